@@ -1,0 +1,403 @@
+"""CPU oracle for the render_rays hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+A numpy restatement of the reference algorithm (Freedomcls/nerf-siren):
+    models/rendering.py:22-67    sample_pdf
+    models/rendering.py:70-262   render_rays (+ nested inference :105-190)
+    models/nerf.py:4-38          Embedding
+    models/nerf.py:41-124        NeRF
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package (nerf_siren_amd/) never does.
+
+Parity status: PINNED.  tests/golden/*.npz hold outputs of the reference itself
+(imported from /root/reference by tools/make_golden.py in the build container);
+tests/test_oracle_golden.py checks every function below against them.
+
+Arithmetic specification ("nerfmi arithmetic").  The reference runs op-by-op in
+fp32 on torch's CPU backend; what is observable there and restated here:
+  * every elementwise op rounds to fp32 once (no fused multiply-add);
+  * torch.linspace(0,1,n)[i] = i<n/2 ? fl(step*i) : fl(1 - step*(n-1-i)) with
+    fp32 step = 1/(n-1) and a single rounding (fma form)       [probed, exact];
+  * torch.cumsum / torch.cumprod accumulate in fp64 and store each prefix
+    rounded to fp32                                             [probed, exact];
+  * torch.sum over a row has an ISA-dependent order: restated as fp64
+    accumulation rounded once (differs from the reference by <= 1 ulp);
+  * torch.searchsorted(cdf, u, right=True) = #{k : cdf[k] <= u}.
+The HIP kernels implement exactly this specification, so kernel == oracle is
+checked much tighter (bit-exact indices/depths given the same inputs) than
+oracle == reference (1e-6 .. 1e-4, see the tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+F64 = np.float64
+
+EPS_PDF = F32(1e-5)        # rendering.py:22 (eps), :37, :63
+T_FLOOR = F32(1e-10)       # rendering.py:175
+DELTA_INF = F32(1e10)      # rendering.py:163
+
+
+# ----------------------------------------------------------------------------
+# primitives
+# ----------------------------------------------------------------------------
+def linspace01(n: int) -> np.ndarray:
+    """torch.linspace(0, 1, n) on CPU, fp32 (rendering.py:207, :44)."""
+    if n == 1:
+        return np.zeros(1, F32)
+    step = F32(F32(1.0) / F32(n - 1))
+    i = np.arange(n)
+    lo = (F64(step) * i).astype(F32)                 # fma(step, i, 0)
+    hi = (1.0 - F64(step) * (n - 1 - i)).astype(F32)  # fma(-step, n-1-i, 1)
+    return np.where(i < n // 2, lo, hi).astype(F32)
+
+
+def searchsorted(a: np.ndarray, v: np.ndarray, side: str = "right") -> np.ndarray:
+    """Row-wise searchsorted with row broadcasting, int64 result.
+
+    torchsearchsorted/src/torchsearchsorted/searchsorted.py:20-53 and
+    test/utils.py:4-15 (numpy_searchsorted); rendering.py:54 uses right=True.
+    """
+    a = np.asarray(a)
+    v = np.asarray(v)
+    nrow = max(a.shape[0], v.shape[0])
+    out = np.empty((nrow, v.shape[1]), np.int64)
+    for r in range(nrow):
+        ra = a[r if a.shape[0] > 1 else 0]
+        rv = v[r if v.shape[0] > 1 else 0]
+        out[r] = np.searchsorted(ra, rv, side=side)
+    return out
+
+
+def embed(x: np.ndarray, n_freqs: int) -> np.ndarray:
+    """Embedding.forward (nerf.py:21-38): [x, sin(2^k x), cos(2^k x)]_{k<n_freqs}.
+
+    2^k * x is exact in fp32; sin/cos are evaluated in fp64 and rounded once
+    (the correctly rounded value any <=1-ulp libm is compared against).
+    """
+    x = np.asarray(x, F32)
+    out = [x]
+    for k in range(n_freqs):
+        arg = (x * F32(2.0 ** k)).astype(F32).astype(F64)
+        out.append(np.sin(arg).astype(F32))
+        out.append(np.cos(arg).astype(F32))
+    return np.concatenate(out, -1)
+
+
+# ----------------------------------------------------------------------------
+# NeRF MLP (nerf.py:41-124), parameters keyed exactly like the state_dict
+# ----------------------------------------------------------------------------
+def _lin(p, name, x):
+    return (x @ p[name + ".weight"].T + p[name + ".bias"]).astype(F32)
+
+
+def nerf_forward(p: dict, x: np.ndarray, sigma_only: bool = False, keep: bool = False):
+    """NeRF.forward (nerf.py:83-124). x: (B,63+27) or (B,63) when sigma_only.
+
+    Returns out (B,4)=[rgb,sigma] or (B,1); with keep=True also the activation
+    cache the manual backward needs.
+    """
+    x = np.asarray(x, F32)
+    in_xyz = x[:, :63]
+    h = in_xyz
+    acts = []                      # inputs of each xyz_encoding layer
+    for i in range(8):
+        if i == 4:                 # skips=[4], nerf.py:108-109
+            h = np.concatenate([in_xyz, h], -1)
+        acts.append(h)
+        h = np.maximum(_lin(p, f"xyz_encoding_{i+1}.0", h), F32(0))
+    sigma = _lin(p, "sigma", h)
+    if sigma_only:
+        return (sigma, dict(acts=acts, h8=h)) if keep else sigma
+    final = _lin(p, "xyz_encoding_final", h)
+    dir_in = np.concatenate([final, x[:, 63:90]], -1)       # nerf.py:118
+    dir_h = np.maximum(_lin(p, "dir_encoding.0", dir_in), F32(0))
+    rgb_pre = _lin(p, "rgb.0", dir_h)
+    rgb = (F32(1) / (F32(1) + np.exp(-rgb_pre.astype(F64)))).astype(F32)
+    out = np.concatenate([rgb, sigma], -1).astype(F32)
+    if keep:
+        return out, dict(acts=acts, h8=h, dir_in=dir_in, dir_h=dir_h, rgb=rgb)
+    return out
+
+
+def nerf_backward(p: dict, cache: dict, grad_out: np.ndarray, sigma_only: bool = False) -> dict:
+    """Manual backward of nerf_forward w.r.t. every parameter (autograd of
+    nerf.py:83-124).  grad_out: (B,4) [d rgb, d sigma] or (B,1)."""
+    g = {}
+    B = grad_out.shape[0]
+    h8 = cache["h8"]
+    if sigma_only:
+        d_sigma = grad_out.reshape(B, 1)
+        d_h8 = np.zeros_like(h8)
+    else:
+        d_rgb = grad_out[:, :3]
+        d_sigma = grad_out[:, 3:4]
+        rgb = cache["rgb"]
+        d_pre = (d_rgb * rgb * (F32(1) - rgb)).astype(F32)
+        g["rgb.0.weight"] = d_pre.T @ cache["dir_h"]
+        g["rgb.0.bias"] = d_pre.sum(0)
+        d_dir_h = d_pre @ p["rgb.0.weight"]
+        d_dir_h = d_dir_h * (cache["dir_h"] > 0)
+        g["dir_encoding.0.weight"] = d_dir_h.T @ cache["dir_in"]
+        g["dir_encoding.0.bias"] = d_dir_h.sum(0)
+        d_final = (d_dir_h @ p["dir_encoding.0.weight"])[:, :256]
+        g["xyz_encoding_final.weight"] = d_final.T @ h8
+        g["xyz_encoding_final.bias"] = d_final.sum(0)
+        d_h8 = d_final @ p["xyz_encoding_final.weight"]
+    g["sigma.weight"] = d_sigma.T @ h8
+    g["sigma.bias"] = d_sigma.sum(0)
+    d_h = d_h8 + d_sigma @ p["sigma.weight"]
+    h_out = h8
+    for i in reversed(range(8)):
+        name = f"xyz_encoding_{i+1}.0"
+        d_pre = (d_h * (h_out > 0)).astype(F32)
+        x_in = cache["acts"][i]
+        g[name + ".weight"] = d_pre.T @ x_in
+        g[name + ".bias"] = d_pre.sum(0)
+        if i == 0:
+            break
+        d_in = d_pre @ p[name + ".weight"]
+        if i == 4:
+            d_in = d_in[:, 63:]
+            h_out = x_in[:, 63:]
+        else:
+            h_out = x_in
+        d_h = d_in
+    return {k: np.asarray(v, F32) for k, v in g.items()}
+
+
+# ----------------------------------------------------------------------------
+# a2  stratified sampler (rendering.py:207-225)
+# ----------------------------------------------------------------------------
+def sample_z(rays: np.ndarray, n_samples: int, use_disp: bool = False,
+             perturb: float = 0.0, perturb_rand: np.ndarray | None = None) -> np.ndarray:
+    """z_vals (N,S). perturb_rand = the torch.rand(N,S) draw of rendering.py:221
+    (before the multiplication by `perturb`)."""
+    rays = np.asarray(rays, F32)
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    t = linspace01(n_samples)[None, :]
+    omt = (F32(1) - t).astype(F32)
+    if not use_disp:
+        z = ((near * omt).astype(F32) + (far * t).astype(F32)).astype(F32)
+    else:
+        inv_n = (F32(1) / near).astype(F32)
+        inv_f = (F32(1) / far).astype(F32)
+        z = (F32(1) / ((inv_n * omt).astype(F32) + (inv_f * t).astype(F32)).astype(F32)).astype(F32)
+    z = np.broadcast_to(z, (rays.shape[0], n_samples)).copy()
+    if perturb > 0:
+        mid = (F32(0.5) * (z[:, :-1] + z[:, 1:]).astype(F32)).astype(F32)
+        upper = np.concatenate([mid, z[:, -1:]], -1)
+        lower = np.concatenate([z[:, :1], mid], -1)
+        pr = (F32(perturb) * np.asarray(perturb_rand, F32)).astype(F32)
+        z = (lower + ((upper - lower).astype(F32) * pr).astype(F32)).astype(F32)
+    return z
+
+
+def points(rays: np.ndarray, z: np.ndarray) -> np.ndarray:
+    """xyz = o + d*z (rendering.py:224-225, :249-250), (N,S,3)."""
+    o, d = rays[:, None, 0:3], rays[:, None, 3:6]
+    return (o + (d * z[:, :, None]).astype(F32)).astype(F32)
+
+
+# ----------------------------------------------------------------------------
+# a8  compositing (rendering.py:162-190) forward + backward
+# ----------------------------------------------------------------------------
+def ray_norm(d: np.ndarray) -> np.ndarray:
+    """torch.norm(dir_, dim=-1) (rendering.py:168): fp32, sequential x,y,z."""
+    d = np.asarray(d, F32)
+    s = ((d[:, 0] * d[:, 0]).astype(F32) + (d[:, 1] * d[:, 1]).astype(F32)).astype(F32)
+    s = (s + (d[:, 2] * d[:, 2]).astype(F32)).astype(F32)
+    return np.sqrt(s).astype(F32)
+
+
+def composite(sigma, rgb, z, rays_d, noise=None, noise_std: float = 0.0,
+              white_back: bool = False, keep: bool = False):
+    """inference() tail, rendering.py:162-190.
+
+    sigma (N,P), rgb (N,P,3) or None (weights_only), z (N,P), rays_d (N,3),
+    noise = the randn(N,P) draw of :170 (before * noise_std) or None.
+    Returns dict(weights, opacity[, rgb, depth]).
+    """
+    sigma = np.asarray(sigma, F32)
+    z = np.asarray(z, F32)
+    N, P = sigma.shape
+    delta = np.empty((N, P), F32)
+    delta[:, :-1] = (z[:, 1:] - z[:, :-1]).astype(F32)
+    delta[:, -1] = DELTA_INF
+    delta = (delta * ray_norm(rays_d)[:, None]).astype(F32)
+    s = sigma
+    if noise is not None:
+        s = (sigma + (np.asarray(noise, F32) * F32(noise_std)).astype(F32)).astype(F32)
+    relu_s = np.maximum(s, F32(0))
+    e = np.exp((-(delta * relu_s).astype(F32)).astype(F64)).astype(F32)
+    alpha = (F32(1) - e).astype(F32)
+    a = ((F32(1) - alpha).astype(F32) + T_FLOOR).astype(F32)     # 1-alpha+1e-10
+    T64 = np.cumprod(np.concatenate([np.ones((N, 1), F64), a[:, :-1].astype(F64)], -1), -1)
+    T = T64.astype(F32)                                          # exclusive product
+    w = (alpha * T).astype(F32)
+    out = {"weights": w, "opacity": w.astype(F64).sum(-1).astype(F32)}
+    if rgb is not None:
+        rgb = np.asarray(rgb, F32)
+        c = (w[:, :, None] * rgb).astype(F32).astype(F64).sum(1).astype(F32)
+        depth = (w * z).astype(F32).astype(F64).sum(-1).astype(F32)
+        if white_back:
+            c = ((c + F32(1)).astype(F32) - out["opacity"][:, None]).astype(F32)
+        out["rgb"] = c
+        out["depth"] = depth
+    if keep:
+        out["_cache"] = dict(delta=delta, s=s, alpha=alpha, a=a, T=T, rgb=rgb, z=z)
+    return out
+
+
+def composite_backward(cache, w, g_rgb, g_depth, g_opacity, white_back: bool):
+    """d loss / d (sigma, rgb) of composite() -- SURVEY section 8a backward
+    contract. g_rgb (N,3), g_depth (N,), g_opacity (N,). fp64 internally."""
+    alpha = cache["alpha"].astype(F64)
+    a = cache["a"].astype(F64)
+    T = cache["T"].astype(F64)
+    rgb = cache["rgb"].astype(F64)
+    z = cache["z"].astype(F64)
+    w = w.astype(F64)
+    g_rgb = g_rgb.astype(F64)
+    v = (rgb * g_rgb[:, None, :]).sum(-1) + z * g_depth[:, None].astype(F64) + g_opacity[:, None].astype(F64)
+    if white_back:
+        v = v - g_rgb.sum(-1)[:, None]
+    d_rgb = w[:, :, None] * g_rgb[:, None, :]
+    wv = w * v
+    suffix = np.cumsum(wv[:, ::-1], -1)[:, ::-1] - wv        # sum_{j>i} w_j v_j
+    d_alpha = T * v - suffix / a
+    d_s = d_alpha * cache["delta"].astype(F64) * (1.0 - alpha) * (cache["s"] > 0)
+    return d_s.astype(F32), d_rgb.astype(F32)
+
+
+# ----------------------------------------------------------------------------
+# a3  sample_pdf (rendering.py:22-67)
+# ----------------------------------------------------------------------------
+def build_cdf(weights: np.ndarray) -> np.ndarray:
+    """rendering.py:36-40. weights (N,nw) -> cdf (N,nw+1) with leading 0."""
+    w = (np.asarray(weights, F32) + EPS_PDF).astype(F32)
+    tot = w.astype(F64).sum(-1, keepdims=True).astype(F32)
+    pdf = (w / tot).astype(F32)
+    cdf = np.cumsum(pdf.astype(F64), -1).astype(F32)
+    return np.concatenate([np.zeros_like(cdf[:, :1]), cdf], -1)
+
+
+def search_lerp(bins: np.ndarray, cdf: np.ndarray, u: np.ndarray):
+    """rendering.py:54-66 given (bins, cdf, u). Returns (inds int64, samples)."""
+    bins = np.asarray(bins, F32)
+    cdf = np.asarray(cdf, F32)
+    u = np.asarray(u, F32)
+    nw = cdf.shape[1] - 1                                   # N_samples_
+    inds = searchsorted(cdf, u, "right")
+    below = np.maximum(inds - 1, 0)
+    above = np.minimum(inds, nw)
+    cdf_b = np.take_along_axis(cdf, below, 1)
+    cdf_a = np.take_along_axis(cdf, above, 1)
+    bin_b = np.take_along_axis(bins, below, 1)
+    bin_a = np.take_along_axis(bins, above, 1)
+    denom = (cdf_a - cdf_b).astype(F32)
+    denom = np.where(denom < EPS_PDF, F32(1), denom)
+    tt = ((u - cdf_b).astype(F32) / denom).astype(F32)
+    samples = (bin_b + (tt * (bin_a - bin_b).astype(F32)).astype(F32)).astype(F32)
+    return inds, samples
+
+
+def sample_pdf(bins, weights, n_importance: int, det: bool = False, u=None):
+    """sample_pdf (rendering.py:22-67). u = the torch.rand(N,F) draw when not det."""
+    cdf = build_cdf(weights)
+    if det:
+        u = np.broadcast_to(linspace01(n_importance)[None, :], (cdf.shape[0], n_importance))
+    inds, samples = search_lerp(bins, cdf, u)
+    return samples, dict(cdf=cdf, inds=inds, u=np.asarray(u, F32))
+
+
+def midpoints(z: np.ndarray) -> np.ndarray:
+    """z_vals_mid (rendering.py:242)."""
+    return (F32(0.5) * (z[:, :-1] + z[:, 1:]).astype(F32)).astype(F32)
+
+
+# ----------------------------------------------------------------------------
+# a1  render_rays (rendering.py:70-262) forward, and the training backward
+# ----------------------------------------------------------------------------
+def _field(p, rays, z, sigma_only, keep):
+    """inference() head, rendering.py:131-159: embed + NeRF per point."""
+    N, P = z.shape
+    xyz = points(rays, z).reshape(-1, 3)
+    x = embed(xyz, 10)
+    if not sigma_only:
+        d_emb = embed(rays[:, 3:6], 4)
+        x = np.concatenate([x, np.repeat(d_emb, P, 0)], -1)
+    r = nerf_forward(p, x, sigma_only, keep)
+    out, cache = r if keep else (r, None)
+    if sigma_only:
+        return out.reshape(N, P), None, cache
+    out = out.reshape(N, P, 4)
+    return out[..., 3], out[..., :3], cache
+
+
+def render_rays(params, rays, N_samples=64, use_disp=False, perturb=0.0, noise_std=1.0,
+                N_importance=0, white_back=False, test_time=False, rng=None, keep=False):
+    """render_rays (rendering.py:70-262). params = [coarse, fine] dicts.
+
+    rng (dict, all optional): perturb_rand (N,S) = draw #1 (:221),
+    noise_coarse (N,S) = draw #2 (:170), u (N,F) = draw #3 (:47),
+    noise_fine (N,S+F) = draw #4; z_fine (N,S+F) overrides the merged depths
+    (test hook: sample_pdf is ill-conditioned in ~zero-weight bins, so stage
+    tests condition on the reference's depths).  Returns the result dict (+ '_aux').
+    """
+    rng = rng or {}
+    rays = np.asarray(rays, F32)
+    d = rays[:, 3:6]
+    z = sample_z(rays, N_samples, use_disp, perturb, rng.get("perturb_rand"))
+    aux = {"z_coarse": z}
+    sig, rgb, mc = _field(params[0], rays, z, test_time, keep)
+    cc = composite(sig, rgb, z, d, rng.get("noise_coarse"), noise_std, white_back, keep)
+    res = {"opacity_coarse": cc["opacity"]}
+    if not test_time:
+        res["rgb_coarse"] = cc["rgb"]
+        res["depth_coarse"] = cc["depth"]
+    aux.update(weights_coarse=cc["weights"], sigma_coarse=sig, rgb_raw_coarse=rgb)
+    if N_importance > 0:
+        zmid = midpoints(z)
+        z_new, pa = sample_pdf(zmid, cc["weights"][:, 1:-1], N_importance,
+                               det=(perturb == 0), u=rng.get("u"))
+        z_all = np.sort(np.concatenate([z, z_new], -1), -1)
+        if "z_fine" in rng:          # test hook: condition on the reference's own merged depths
+            z_all = np.asarray(rng["z_fine"], F32)
+        sig_f, rgb_f, mf = _field(params[1], rays, z_all, False, keep)
+        cf = composite(sig_f, rgb_f, z_all, d, rng.get("noise_fine"), noise_std, white_back, keep)
+        res["rgb_fine"] = cf["rgb"]
+        res["depth_fine"] = cf["depth"]
+        res["opacity_fine"] = cf["opacity"]
+        aux.update(z_new=z_new, z_fine=z_all, cdf=pa["cdf"], inds=pa["inds"],
+                   weights_fine=cf["weights"], sigma_fine=sig_f, rgb_raw_fine=rgb_f)
+        if keep:
+            aux["_fine"] = (mf, cf)
+    if keep:
+        aux["_coarse"] = (mc, cc)
+    res["_aux"] = aux
+    return res
+
+
+def render_rays_backward(params, res, grads, white_back=False):
+    """Parameter gradients of a training-mode render_rays() call made with
+    keep=True.  grads: dict name -> dL/d(output) for any of rgb_/depth_/opacity_
+    {coarse,fine}.  Returns [g_coarse, g_fine] (fine None when absent).
+    No gradient crosses sample_pdf (rendering.py:54 cdf.detach(), :244 .detach())."""
+    aux = res["_aux"]
+    out = []
+    for tag in ("coarse", "fine"):
+        key = "_" + tag
+        if key not in aux:
+            out.append(None)
+            continue
+        mcache, cres = aux[key]
+        N = cres["weights"].shape[0]
+        zero = np.zeros(N, F32)
+        g_rgb = grads.get("rgb_" + tag, np.zeros((N, 3), F32))
+        g_dep = grads.get("depth_" + tag, zero)
+        g_op = grads.get("opacity_" + tag, zero)
+        d_s, d_rgb = composite_backward(cres["_cache"], cres["weights"], g_rgb, g_dep, g_op, white_back)
+        g_out = np.concatenate([d_rgb, d_s[:, :, None]], -1).reshape(-1, 4)
+        out.append(nerf_backward(params[0 if tag == "coarse" else 1], mcache, g_out))
+    return out

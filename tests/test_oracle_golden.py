@@ -1,0 +1,206 @@
+"""Pin the CPU oracle (oracle/nerf_oracle.py) to the reference's own outputs
+(tests/golden/*.npz, produced by tools/make_golden.py from /root/reference).
+
+Tolerances: bit-exact where the arithmetic is specified (linspace, z values,
+cumsum/cumprod given equal inputs, searchsorted indices given equal (cdf,u));
+a few ulp where torch's CPU kernels have an unspecified order or libm (row
+sums, torch.norm, exp/sin/cos); 1e-4 abs end to end (north_star)."""
+import numpy as np
+import pytest
+
+from nerf_siren_amd import synth
+from oracle import nerf_oracle as O
+
+
+def test_linspace(golden):
+    g = golden("g1_sampler")
+    for n in (2, 3, 64, 65, 128, 192):
+        assert np.array_equal(O.linspace01(n), g[f"linspace_{n}"])
+
+
+@pytest.mark.parametrize("S", [64, 17])
+@pytest.mark.parametrize("disp", [0, 1])
+@pytest.mark.parametrize("pert", [0.0, 1.0, 0.5])
+def test_sampler_bit_exact(golden, S, disp, pert):
+    g = golden("g1_sampler")
+    tag = f"S{S}_disp{disp}_p{pert}"
+    rays = g["rays_" + tag]
+    z = O.sample_z(rays, S, bool(disp), pert, g["prand_" + tag])
+    xyz = O.points(rays, z)
+    assert np.array_equal(xyz, g["xyz_" + tag])
+
+
+def test_embedding(golden):
+    g = golden("g2_embedding")
+    assert np.abs(O.embed(g["x"], 10) - g["emb10"]).max() <= 2.4e-7   # 2 ulp of 1.0
+    assert np.abs(O.embed(g["x"], 4) - g["emb4"]).max() <= 2.4e-7
+    assert np.array_equal(O.embed(g["x"], 10)[:, :3], g["x"])
+
+
+def test_nerf_mlp(golden):
+    g = golden("g3_nerf")
+    p = synth.nerf_params(1)
+    out = O.nerf_forward(p, g["x"])
+    assert np.abs(out[:, :3] - g["out"][:, :3]).max() < 2e-6
+    np.testing.assert_allclose(out[:, 3], g["out"][:, 3], rtol=2e-5, atol=2e-5)
+    sig = O.nerf_forward(p, g["x"][:, :63], sigma_only=True)
+    np.testing.assert_allclose(sig, g["sigma"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_composite(golden, tag):
+    g = golden("g4_composite")
+    r = O.composite(g[tag + "_sigma"], g[tag + "_rgb"], _z(g[tag + "_rays"], g[tag + "_sigma"].shape[1]),
+                    g[tag + "_rays"][:, 3:6], g[tag + "_noise"], float(g[tag + "_noise_std"]),
+                    bool(g[tag + "_white_back"]))
+    np.testing.assert_allclose(r["rgb"], g[tag + "_out_rgb"], atol=5e-7, rtol=0)
+    np.testing.assert_allclose(r["opacity"], g[tag + "_out_opacity"], atol=5e-7, rtol=0)
+    np.testing.assert_allclose(r["depth"], g[tag + "_out_depth"], atol=3e-6, rtol=0)
+    np.testing.assert_allclose(r["weights"][:, 1:-1], g[tag + "_weights_inner"], atol=1.2e-7, rtol=1e-6)
+    # edge rows (tools/make_golden.py g_composite): transparent, negative, opaque
+    if tag == "a":                                            # noise_std == 0
+        assert r["opacity"][0] == 0 and r["opacity"][1] == 0
+        assert abs(r["opacity"][2] - 1) < 1e-6 and abs(r["opacity"][3] - 1) < 1e-6
+
+
+def _z(rays, P):
+    return O.sample_z(rays, P)
+
+
+@pytest.mark.parametrize("case", ["det", "rnd", "tie"])
+def test_sample_pdf_stage2_bit_exact(golden, case):
+    """search+lerp on the reference's own (cdf,u): indices and samples bit-exact."""
+    g = golden("g5_sample_pdf")
+    inds, samples = O.search_lerp(g["bins"], g[case + "_cdf"], g[case + "_u"])
+    assert np.array_equal(inds, g[case + "_inds"])
+    assert np.array_equal(samples, g[case + "_samples"])
+    assert inds.dtype == np.int64
+
+
+def test_sample_pdf_stage1_cdf(golden):
+    g = golden("g5_sample_pdf")
+    cdf = O.build_cdf(g["weights"])
+    # row-sum order differs from torch's vectorised sum by <=1 ulp of the total;
+    # the cumsum itself is bit-equal given the same pdf.
+    np.testing.assert_allclose(cdf, g["det_cdf"], atol=2.4e-7, rtol=0)
+    frac = (cdf == g["det_cdf"]).mean()
+    assert frac > 0.5
+    s, aux = O.sample_pdf(g["bins"], g["weights"], 64, det=True)
+    agree = (aux["inds"] == g["det_inds"]).mean()
+    assert agree > 0.99, agree
+    s2, aux2 = O.sample_pdf(g["bins"][:, :20], g["weights"][:, :19], 37, det=True)
+    assert (aux2["inds"] == g["odd_inds"]).mean() > 0.99
+    assert np.abs(s2 - g["odd_samples"]).max() < 0.15  # a flipped index moves one sample by <= one bin
+
+
+def test_searchsorted_matrix(golden):
+    g = golden("g5_searchsorted")
+    a, v = g["a"], g["v"]
+    for nm, (aa, vv) in dict(full=(a, v), bca=(a[:1], v), bcv=(a, v[:1])).items():
+        for side in ("left", "right"):
+            assert np.array_equal(O.searchsorted(aa, vv, side), g[f"{nm}_{side}"])
+
+
+RENDER_CASES = ["blender_det", "blender_train", "ndc_train", "blender_test_time", "blender_disp",
+                "coarse_only", "odd_sizes"]
+
+
+def run_oracle_case(g, keep=False):
+    F = int(g["F"])
+    params = [synth.nerf_params(1, sigma_bias=-1.0), synth.nerf_params(2, sigma_bias=0.5)]
+    rng = {k[4:]: g[k] for k in g if k.startswith("rng_")}
+    return params, O.render_rays(params, g["rays"], int(g["S"]), bool(g["use_disp"]), float(g["perturb"]),
+                                 float(g["noise_std"]), F, bool(g["white_back"]), bool(g["test_time"]),
+                                 rng=rng, keep=keep)
+
+
+@pytest.mark.parametrize("case", RENDER_CASES)
+def test_render_rays_end_to_end(golden, case):
+    g = golden("g7_" + case)
+    _, res = run_oracle_case(g)
+    keys = [k[4:] for k in g if k.startswith("out_")]
+    assert set(keys) == set(k for k in res if not k.startswith("_"))
+    span = float((g["rays"][:, 7] - g["rays"][:, 6]).max())
+    N = g["rays"].shape[0]
+    flipped = np.zeros(N, bool)
+    if int(g["F"]) > 0:
+        # One ulp of cdf (torch's row-sum order is ISA dependent) can flip a
+        # searchsorted index and move that fine sample by up to one coarse bin
+        # (SURVEY section 7 'bit-exact sample indices', section 8 a3): such rays
+        # are listed and held to a looser bound; all others to 1e-4.
+        mism = res["_aux"]["inds"] != g["mid_inds"]
+        flipped = mism.any(1)
+        assert mism.mean() < 0.03, mism.mean()
+        assert np.all(np.diff(res["_aux"]["z_fine"], axis=-1) >= 0)
+    for k in keys:
+        tol = 1e-4 * (span if "depth" in k else 1.0)       # SURVEY section 7 contract (iii)
+        err = np.abs(res[k] - g["out_" + k]).reshape(N, -1).max(-1)
+        loose = flipped & np.array(["fine" in k] * N)
+        assert np.all(err[~loose] <= tol), (k, err[~loose].max())
+        assert np.all(err[loose] <= 100 * tol), (k, err[loose].max())
+
+
+def _loss_grads(g, res):
+    """d loss / d outputs for the loss of tools/make_golden.py g_render."""
+    N = g["rays"].shape[0]
+    t = g["target"]
+    grads = {"rgb_coarse": 2 * (res["rgb_coarse"] - t) / (3 * N), "depth_coarse": np.full(N, 0.1 / N, np.float32),
+             "opacity_coarse": np.full(N, 0.3 / N, np.float32)}
+    if int(g["F"]) > 0:
+        grads.update({"rgb_fine": 2 * (res["rgb_fine"] - t) / (3 * N),
+                      "depth_fine": 0.2 * 2 * res["depth_fine"] / N,
+                      "opacity_fine": np.full(N, -0.1 / N, np.float32)})
+    return grads
+
+
+def grad_rel_errors(g, gs):
+    """max over tensors of ||mine - ref|| / ||ref|| per model (subsampled for big tensors)."""
+    worst = []
+    for mi, gm in enumerate(gs):
+        if gm is None:
+            continue
+        w = 0.0
+        for k, v in gm.items():
+            ref = g.get(f"grad{mi}_{k}")
+            mine = np.asarray(v)
+            if ref is None:
+                ref = g[f"grad{mi}_{k}_sub"]
+                mine = mine.reshape(-1)[::37]
+            else:
+                nrm = float(g[f"grad{mi}_{k}_norm"])
+                assert abs(np.linalg.norm(mine.astype(np.float64)) - nrm) <= 2e-2 * nrm + 1e-9
+            den = np.linalg.norm(ref.astype(np.float64)) + 1e-12
+            w = max(w, float(np.linalg.norm(mine.reshape(-1).astype(np.float64) - ref.reshape(-1)) / den))
+        worst.append(w)
+    return worst
+
+
+GRAD_CASES = ["blender_train", "ndc_train", "blender_disp", "coarse_only", "odd_sizes", "blender_det"]
+
+
+@pytest.mark.parametrize("case", GRAD_CASES)
+def test_render_rays_gradients(golden, case):
+    """Manual backward of the oracle == autograd of the reference.
+
+    Typical agreement is 1e-6 relative; the bound is 5e-3 because a ReLU whose
+    pre-activation is ~0 can land on either side under a different fp32 GEMM
+    summation order (MKL vs OpenBLAS here), which switches that unit's whole
+    gradient path on or off (seen in blender_disp: layers <= 6 at 1e-3).
+    Fine-model gradients additionally inherit sample_pdf's ill-conditioning (a
+    1-ulp cdf change moves samples in ~zero-weight bins): 2e-2 end to end, 5e-3
+    once conditioned on the reference's own merged depths (rng['z_fine'])."""
+    g = golden("g7_" + case)
+    params, res = run_oracle_case(g, keep=True)
+    gs = O.render_rays_backward(params, res, _loss_grads(g, res), bool(g["white_back"]))
+    w = grad_rel_errors(g, gs)
+    assert w[0] < 5e-3, w
+    if len(w) > 1:
+        assert w[1] < 2e-2, w
+        g2 = dict(g)
+        g2["rng_z_fine"] = g["mid_sort_out"]
+        params, res = run_oracle_case(g2, keep=True)
+        gs = O.render_rays_backward(params, res, _loss_grads(g, res), bool(g["white_back"]))
+        w = grad_rel_errors(g, gs)
+        assert w[0] < 5e-3 and w[1] < 5e-3, w
+        for k in ("rgb_fine", "depth_fine", "opacity_fine"):
+            assert np.abs(res[k] - g["out_" + k]).max() < 3e-6, k

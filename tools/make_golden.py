@@ -1,0 +1,315 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported from
+/root/reference, CPU, fp32) on seeded synthetic inputs.
+
+Runs only in the build container (the reference never travels to the GPU box).
+The fixtures are data: inputs + the reference's outputs.  Re-run with
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+RNG: torch.rand / torch.randn are patched to return hash-based tensors
+(nerf_siren_amd.synth) in the reference's draw order (rand(N,S),
+randn(N,S), rand(N,F), randn(N,S+F)) and those tensors are stored as inputs.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+import models.rendering as R                      # noqa: E402  (reference)
+from models.nerf import Embedding, NeRF           # noqa: E402  (reference)
+from nerf_siren_amd import synth                  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    arrs = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print(f"{name}: " + ", ".join(f"{k}{list(v.shape)}" for k, v in arrs.items()))
+
+
+def ref_model(params):
+    m = NeRF()
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    return m
+
+
+class Recorder:
+    """Patches torch.rand/randn/searchsorted/sort to inject RNG and record
+    the reference's intermediates."""
+
+    def __init__(self, rng):
+        self.rng = list(rng)
+        self.rec = {}
+
+    def __enter__(self):
+        self._rand, self._randn = torch.rand, torch.randn
+        self._ss, self._sort, self._pdf = torch.searchsorted, torch.sort, R.sample_pdf
+        rec = self.rec
+
+        def take(kind, shape):
+            shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+            k, t = self.rng.pop(0)
+            assert k == kind and tuple(t.shape) == shape, (k, kind, t.shape, shape)
+            return torch.from_numpy(t.copy())
+
+        def rand(*shape, **kw):
+            return take("rand", shape)
+
+        def randn(*shape, **kw):
+            return take("randn", shape)
+
+        def ss(cdf, u, right=False, **kw):
+            inds = self._ss(cdf, u, right=right, **kw)
+            rec["cdf"], rec["u"], rec["inds"] = cdf.clone(), u.clone(), inds.clone()
+            return inds
+
+        def sort(x, dim=-1, **kw):
+            r = self._sort(x, dim, **kw)
+            rec["sort_in"], rec["sort_out"] = x.detach().clone(), r[0].detach().clone()
+            return r
+
+        def pdf(bins, weights, n, det=False, eps=1e-5):
+            rec["pdf_bins"], rec["pdf_weights"] = bins.detach().clone(), weights.detach().clone()
+            out = self._pdf(bins, weights, n, det=det, eps=eps)
+            rec["pdf_samples"] = out.detach().clone()
+            return out
+
+        torch.rand, torch.randn, torch.searchsorted, torch.sort = rand, randn, ss, sort
+        R.sample_pdf = pdf
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.randn, torch.searchsorted, torch.sort = self._rand, self._randn, self._ss, self._sort
+        R.sample_pdf = self._pdf
+        assert not self.rng, "unused RNG tensors"
+
+
+class StubField(torch.nn.Module):
+    """A 'model' that returns preset (rgb, sigma) rows: exposes the reference's
+    compositing (rendering.py:162-190) on chosen inputs."""
+
+    def __init__(self, rgbsigma):
+        super().__init__()
+        self.v = rgbsigma
+        self.pos = 0
+
+    def forward(self, x, sigma_only=False):
+        n = x.shape[0]
+        out = self.v[self.pos:self.pos + n]
+        self.pos += n
+        return out[:, 3:4] if sigma_only else out
+
+
+EMB = [Embedding(3, 10), Embedding(3, 4)]
+
+
+# --------------------------------------------------------------------------- G1/G2/G3
+def g_primitives():
+    rays = np.concatenate([synth.blender_rays(5, 3), synth.ndc_rays(4, 3)], 0)
+    rays[7, 6] = 0.05                              # keep 1/near finite for disparity
+    rays_t = torch.from_numpy(rays)
+    out = {"rays": rays}
+    for n in (2, 3, 64, 65, 128, 192):
+        out[f"linspace_{n}"] = torch.linspace(0, 1, n)
+    # z_vals through the reference: N_importance=0 with a stub field, capture xyz
+    for S in (64, 17):
+        for disp in (False, True):
+            for pert in (0.0, 1.0, 0.5):
+                pr = synth.hash_uniform((rays.shape[0], S), 100 + S)
+                grab = {}
+
+                class Grab(torch.nn.Module):
+                    def forward(self, x, sigma_only=False):
+                        grab["x"] = x.clone()
+                        return torch.zeros(x.shape[0], 4)
+
+                rng = ([("rand", pr)] if pert > 0 else []) + [("randn", np.zeros((rays.shape[0], S), np.float32))]
+                r2 = rays.copy()
+                if disp:
+                    r2[:, 6] = np.maximum(r2[:, 6], 0.05)
+                with Recorder(rng):
+                    R.render_rays([Grab()], [lambda x: x, EMB[1]], torch.from_numpy(r2), S, disp, pert, 0, 0,
+                                  1 << 20, False, False)
+                xyz = grab["x"][:, :3].reshape(rays.shape[0], S, 3)
+                tag = f"S{S}_disp{int(disp)}_p{pert}"
+                out["xyz_" + tag] = xyz
+                out["rays_" + tag] = r2
+                out["prand_" + tag] = pr
+    save("g1_sampler", **out)
+
+    x = (synth.hash_uniform((257, 3), 5) * 12 - 6).astype(np.float32)
+    x[0] = 0
+    x[1] = [6, -6, 1e-3]
+    save("g2_embedding", x=x, emb10=EMB[0](torch.from_numpy(x)), emb4=EMB[1](torch.from_numpy(x)))
+
+    p = synth.nerf_params(1)
+    m = ref_model(p)
+    xin = EMB[0](torch.from_numpy((synth.hash_uniform((200, 3), 6) * 8 - 4).astype(np.float32)))
+    din = EMB[1](torch.from_numpy(synth.blender_rays(200, 6)[:, 3:6]))
+    xfull = torch.cat([xin, din], -1)
+    with torch.no_grad():
+        save("g3_nerf", x=xfull, out=m(xfull), sigma=m(xin, sigma_only=True))
+
+
+# --------------------------------------------------------------------------- G4
+def g_composite():
+    out = {}
+    for tag, P, wb, nstd in (("a", 64, True, 0.0), ("b", 128, False, 1.0), ("c", 64, True, 0.7)):
+        N = 40
+        rays = synth.blender_rays(N, 10) if wb else synth.ndc_rays(N, 10)
+        sig = (synth.hash_normal((N, P), 20 + P) * 3).astype(np.float32)
+        rgb = synth.hash_uniform((N, P, 3), 21 + P)
+        sig[0] = 0                               # transparent ray
+        sig[1] = -5                              # all negative
+        sig[2] = 1e4                             # alpha -> 1 at the first sample
+        sig[3, :-1] = 0
+        sig[3, -1] = 1e-3                        # only the 1e10 far-plane delta
+        sig[4] = 1e-6
+        noise = synth.hash_normal((N, P), 22 + P)
+        stub = StubField(torch.from_numpy(np.concatenate([rgb, sig[..., None]], -1).reshape(-1, 4)))
+        with Recorder([("randn", noise)]) as rec:
+            res = R.render_rays([stub], EMB, torch.from_numpy(rays), P, False, 0, nstd, 0, 1 << 20, wb, False)
+        # weights: re-run with N_importance>0 and a dummy fine stub to reach sample_pdf's input
+        stub2 = StubField(torch.from_numpy(np.concatenate([rgb, sig[..., None]], -1).reshape(-1, 4)))
+        fine = StubField(torch.zeros(N * (P + 4), 4))
+        with Recorder([("randn", noise), ("randn", np.zeros((N, P + 4), np.float32))]) as rec:
+            R.render_rays([stub2, fine], EMB, torch.from_numpy(rays), P, False, 0, nstd, 4, 1 << 20, wb, False)
+        out.update({f"{tag}_rays": rays, f"{tag}_sigma": sig, f"{tag}_rgb": rgb, f"{tag}_noise": noise,
+                    f"{tag}_noise_std": nstd, f"{tag}_white_back": wb,
+                    f"{tag}_out_rgb": res["rgb_coarse"], f"{tag}_out_depth": res["depth_coarse"],
+                    f"{tag}_out_opacity": res["opacity_coarse"],
+                    f"{tag}_weights_inner": rec.rec["pdf_weights"]})
+    save("g4_composite", **out)
+
+
+# --------------------------------------------------------------------------- G5/G6
+def g_sample_pdf():
+    N, S, F = 48, 64, 64
+    z = np.sort(synth.hash_uniform((N, S), 30) * 4 + 2, -1).astype(np.float32)
+    bins = (0.5 * (z[:, :-1] + z[:, 1:])).astype(np.float32)
+    w = synth.hash_uniform((N, S - 2), 31) ** 8          # peaked
+    w[0] = 0                                            # zero weights -> denom<eps path
+    w[1] = 0
+    w[1, 30] = 1.0                                      # one spike
+    w[2] = 1.0                                          # flat
+    w[3, :31] = 0                                       # long zero plateau then mass
+    w[4, 31:] = 0
+    out = {"bins": bins, "weights": w}
+    with Recorder([]) as rec:
+        s = R.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), F, det=True)
+    out.update(det_samples=s, det_cdf=rec.rec["cdf"], det_inds=rec.rec["inds"], det_u=rec.rec["u"])
+    u = synth.hash_uniform((N, F), 32)
+    u[5, :4] = [0.0, 1.0 - 2 ** -24, 0.5, 0.25]
+    with Recorder([("rand", u)]) as rec:
+        s = R.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), F, det=False)
+    out.update(rnd_samples=s, rnd_cdf=rec.rec["cdf"], rnd_inds=rec.rec["inds"], rnd_u=u)
+    # ties: u exactly equal to cdf entries (searchsorted right => index after the tie)
+    cdf = rec.rec["cdf"].numpy()
+    u2 = cdf[:, np.minimum(np.arange(F), S - 2)].copy()
+    with Recorder([("rand", u2)]) as rec:
+        s = R.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), F, det=False)
+    out.update(tie_samples=s, tie_cdf=rec.rec["cdf"], tie_inds=rec.rec["inds"], tie_u=u2)
+    # F != S, odd sizes
+    with Recorder([]) as rec:
+        s = R.sample_pdf(torch.from_numpy(bins[:, :20]), torch.from_numpy(w[:, :19]), 37, det=True)
+    out.update(odd_samples=s, odd_cdf=rec.rec["cdf"], odd_inds=rec.rec["inds"])
+    save("g5_sample_pdf", **out)
+
+    # generic searchsorted (torchsearchsorted test matrix shapes, incl. broadcasting + ties)
+    a = np.sort(synth.hash_uniform((7, 50), 40), -1)
+    v = synth.hash_uniform((7, 12), 41)
+    v[:, :3] = a[:, [0, 10, 49]]
+    a1 = a[:1]
+    v1 = v[:1]
+    ss = {}
+    for nm, (aa, vv) in dict(full=(a, v), bca=(a1, v), bcv=(a, v1)).items():
+        A = torch.from_numpy(np.broadcast_to(aa, (7, 50)).copy())
+        V = torch.from_numpy(np.broadcast_to(vv, (7, 12)).copy())
+        ss[nm + "_right"] = torch.searchsorted(A, V, right=True)
+        ss[nm + "_left"] = torch.searchsorted(A, V, right=False)
+    save("g5_searchsorted", a=a, v=v, **ss)
+
+
+# --------------------------------------------------------------------------- G7
+def subsample(g):
+    g = g.reshape(-1)
+    return g[::37].copy()
+
+
+def g_render(tag, rays, S, F, use_disp, perturb, noise_std, white_back, test_time, seed, backward=True):
+    N = rays.shape[0]
+    pc = synth.nerf_params(1, sigma_bias=-1.0)
+    pf = synth.nerf_params(2, sigma_bias=0.5)
+    models = [ref_model(pc)] + ([ref_model(pf)] if F > 0 else [])
+    rng, store = [], {}
+    if perturb > 0:
+        store["perturb_rand"] = synth.hash_uniform((N, S), seed + 1)
+        rng.append(("rand", store["perturb_rand"]))
+    store["noise_coarse"] = synth.hash_normal((N, S), seed + 2)
+    rng.append(("randn", store["noise_coarse"]))
+    if F > 0:
+        if perturb > 0:
+            store["u"] = synth.hash_uniform((N, F), seed + 3)
+            rng.append(("rand", store["u"]))
+        store["noise_fine"] = synth.hash_normal((N, S + F), seed + 4)
+        rng.append(("randn", store["noise_fine"]))
+    target = synth.hash_uniform((N, 3), seed + 5)
+    grad_ctx = torch.enable_grad() if (backward and not test_time) else torch.no_grad()
+    with grad_ctx, Recorder(rng) as rec:
+        res = R.render_rays(models, EMB, torch.from_numpy(rays), S, use_disp, perturb, noise_std, F,
+                            1024 * 32, white_back, test_time)
+    out = dict(rays=rays, target=target, **{"rng_" + k: v for k, v in store.items()})
+    out.update({"out_" + k: v for k, v in res.items()})
+    for k in ("cdf", "u", "inds", "sort_out", "pdf_weights", "pdf_samples"):
+        if k in rec.rec:
+            out["mid_" + k] = rec.rec[k]
+    if backward and not test_time:
+        # losses.py:15-20 MSE(coarse)+MSE(fine), plus depth/opacity terms so that
+        # every output's gradient path is exercised.
+        t = torch.from_numpy(target)
+        loss = ((res["rgb_coarse"] - t) ** 2).mean() + 0.1 * res["depth_coarse"].mean() + 0.3 * res["opacity_coarse"].mean()
+        if F > 0:
+            loss = loss + ((res["rgb_fine"] - t) ** 2).mean() + 0.2 * (res["depth_fine"] ** 2).mean() \
+                - 0.1 * res["opacity_fine"].mean()
+        loss.backward()
+        out["loss"] = loss.detach()
+        for mi, m in enumerate(models):
+            for k, v in m.named_parameters():
+                g = v.grad
+                key = f"grad{mi}_{k}"
+                if g.numel() <= 4096:
+                    out[key] = g
+                else:
+                    out[key + "_sub"] = subsample(g.numpy())
+                out[key + "_norm"] = g.double().norm().float()
+                out[key + "_sum"] = g.double().sum().float()
+    save("g7_" + tag, S=S, F=F, use_disp=use_disp, perturb=perturb, noise_std=noise_std,
+         white_back=white_back, test_time=test_time, **out)
+
+
+def main():
+    g_primitives()
+    g_composite()
+    g_sample_pdf()
+    bl = synth.blender_rays(48, 50)
+    nd = synth.ndc_rays(40, 51)
+    g_render("blender_det", bl, 64, 64, False, 0.0, 0.0, True, False, 1000)
+    g_render("blender_train", bl, 64, 64, False, 1.0, 1.0, True, False, 1010)
+    g_render("ndc_train", nd, 64, 64, False, 1.0, 0.0, False, False, 1020)
+    g_render("blender_test_time", bl, 64, 64, False, 0.0, 0.0, True, True, 1030)
+    bd = bl.copy()
+    g_render("blender_disp", bd, 64, 64, True, 0.5, 0.3, True, False, 1040)
+    g_render("coarse_only", synth.blender_rays(64, 52, img_wh=(64, 64)), 64, 0, False, 1.0, 1.0, True, False, 1050)
+    g_render("odd_sizes", bl[:9], 24, 40, False, 1.0, 1.0, False, False, 1060)
+
+
+if __name__ == "__main__":
+    main()
