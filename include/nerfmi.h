@@ -1,0 +1,140 @@
+/*
+ * nerfmi.h -- C ABI of the MI355X-native volumetric-rendering hot path.
+ *
+ * Drop-in boundary for Freedomcls/nerf-siren's render_rays() path.  The
+ * reference has no FFI of its own here (the path is torch tensor code behind
+ * the Python signature models/rendering.py:70-83); its native-plugin convention
+ * (torch_utils/custom_ops.py:61, torchsearchsorted/src/cuda/
+ * searchsorted_cuda_wrapper.cpp:9-20) is caller-allocated tensors + contiguity
+ * checks + launch on the current stream.  This header keeps that shape without
+ * torch types: plain device pointers, explicit sizes, an explicit hipStream_t.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major fp32 unless
+ *     stated; outputs are caller-allocated; nothing is allocated or freed here;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - launches are asynchronous; the functions never synchronise;
+ *   - return 0 on success, <0 on error (NERFMI_E_*); the message of the last
+ *     error on the calling thread is nerfmi_last_error();
+ *   - no global mutable state besides that thread-local message: re-entrant
+ *     across streams and threads.
+ */
+#ifndef NERFMI_H
+#define NERFMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERFMI_OK 0
+#define NERFMI_E_INVALID (-1) /* bad argument (null pointer, size out of range) */
+#define NERFMI_E_LAUNCH (-2)  /* HIP reported a launch/runtime error            */
+#define NERFMI_E_UNSUPPORTED (-3)
+
+typedef void *nerfmi_stream_t;
+
+int nerfmi_version(void);
+const char *nerfmi_last_error(void);
+
+/* ---- a2: stratified sampler -- models/rendering.py:207-222 ---------------
+ * rays (n_rays,8) = [o(3) d(3) near far]; perturb_rand (n_rays,n_samples) is the
+ * torch.rand draw of :221 (may be NULL when perturb == 0);  z_out (n_rays,n_samples). */
+int nerfmi_sample_stratified(const float *rays, const float *perturb_rand, int n_rays, int n_samples,
+                             int use_disp, float perturb, float *z_out, nerfmi_stream_t stream);
+
+/* ---- a5: Embedding.forward -- models/nerf.py:21-38 -----------------------
+ * x (n,3) -> out (n, 3*(2*n_freqs+1)) = [x, sin(2^k x), cos(2^k x)]_k. */
+int nerfmi_embed(const float *x, int64_t n, int n_freqs, float *out, nerfmi_stream_t stream);
+
+/* ---- a6: NeRF MLP -- models/nerf.py:41-124 -------------------------------
+ * Parameters are handed over once per weight update as the 24 state_dict
+ * tensors in nerf.py:61-81 order (weight (out,in) row-major, then bias):
+ *   xyz_encoding_{1..8}.0.{weight,bias}, xyz_encoding_final.{weight,bias},
+ *   dir_encoding.0.{weight,bias}, sigma.{weight,bias}, rgb.0.{weight,bias}
+ * and repacked into MFMA-fragment order (`packed`, nerfmi_nerf_packed_floats()
+ * floats) -- forward and transposed (for the backward dX chain) images.
+ * `params` is a HOST array of 24 DEVICE pointers. */
+size_t nerfmi_nerf_packed_floats(void);
+int nerfmi_nerf_pack(const float *const *params, float *packed, nerfmi_stream_t stream);
+
+/* Fused inference() head (rendering.py:131-159): for every sample p of every
+ * ray: xyz = o + d*z, Embedding(3,10), Embedding(3,4)(d), NeRF.forward.
+ * z (n_rays,n_per_ray).  out: (n_rays*n_per_ray,4) [rgb,sigma] or, when
+ * sigma_only, (n_rays*n_per_ray,1).
+ * saved: NULL for inference, else nerfmi_nerf_saved_floats(n_points) floats of
+ * activations kept for nerfmi_nerf_backward_rays (training).  */
+size_t nerfmi_nerf_saved_floats(int64_t n_points);
+int nerfmi_nerf_forward_rays(const float *packed, const float *rays, const float *z, int n_rays, int n_per_ray,
+                             int sigma_only, float *out, float *saved, nerfmi_stream_t stream);
+
+/* NeRF.forward(x, sigma_only) on pre-embedded rows x (n, 90) / (n, 63)
+ * (nerf.py:83-124) -- the module-level API (dense grid queries,
+ * extract_color_mesh.py:117-143). */
+int nerfmi_nerf_forward_embedded(const float *packed, const float *x, int64_t n, int sigma_only, float *out,
+                                 nerfmi_stream_t stream);
+
+/* Backward of nerfmi_nerf_forward_rays w.r.t. the 24 parameters.
+ * grad_out (n_points,4) = dL/d[rgb,sigma].  grad_params: HOST array of 24
+ * DEVICE pointers, same order/shapes as `params`; gradients are WRITTEN (not
+ * accumulated).  workspace: nerfmi_nerf_backward_workspace_floats(n_points). */
+size_t nerfmi_nerf_backward_workspace_floats(int64_t n_points);
+int nerfmi_nerf_backward_rays(const float *packed, const float *rays, const float *z, int n_rays, int n_per_ray,
+                              const float *saved, const float *grad_out, float *const *grad_params,
+                              float *workspace, nerfmi_stream_t stream);
+
+/* ---- a8: compositing -- models/rendering.py:162-190 ----------------------
+ * field: (n_rays,n_per_ray,4) [rgb,sigma] or, when sigma_only, (n_rays,n_per_ray)
+ * sigma (the weights_only branch :179-180: only weights/opacity are produced).
+ * noise (n_rays,n_per_ray) = the torch.randn draw of :170 or NULL (noise_std 0).
+ * Outputs (each may be NULL except weights_out/opacity_out when sigma_only):
+ *   weights_out (n_rays,n_per_ray), rgb_out (n_rays,3), depth_out, opacity_out (n_rays). */
+int nerfmi_composite(const float *field, int sigma_only, const float *z, const float *rays, const float *noise,
+                     float noise_std, int n_rays, int n_per_ray, int white_back, float *weights_out,
+                     float *rgb_out, float *depth_out, float *opacity_out, nerfmi_stream_t stream);
+
+/* Backward of nerfmi_composite: d loss/d field given d loss/d (rgb,depth,opacity)
+ * (any of g_* may be NULL = zero).  grad_field (n_rays,n_per_ray,4). */
+int nerfmi_composite_backward(const float *field, const float *z, const float *rays, const float *noise,
+                              float noise_std, int n_rays, int n_per_ray, int white_back, const float *g_rgb,
+                              const float *g_depth, const float *g_opacity, float *grad_field,
+                              nerfmi_stream_t stream);
+
+/* ---- a3: sample_pdf -- models/rendering.py:22-67 -------------------------
+ * bins (n_rays,n_weights+1), weights (n_rays,n_weights); u (n_rays,n_importance)
+ * = the torch.rand draw of :47, or NULL for det=True (u = linspace(0,1,F)).
+ * Optional outputs (NULL to skip): cdf_out (n_rays,n_weights+1),
+ * inds_out (n_rays,n_importance) int64 (torch.searchsorted(right=True)).  */
+int nerfmi_sample_pdf(const float *bins, const float *weights, const float *u, int n_rays, int n_weights,
+                      int n_importance, float *cdf_out, int64_t *inds_out, float *samples_out,
+                      nerfmi_stream_t stream);
+
+/* Stage 2 alone (rendering.py:54-66) on a caller-supplied cdf. */
+int nerfmi_search_lerp(const float *bins, const float *cdf, const float *u, int n_rays, int n_weights,
+                       int n_importance, int64_t *inds_out, float *samples_out, nerfmi_stream_t stream);
+
+/* Row-wise searchsorted with row broadcasting -- torchsearchsorted/src/cuda/
+ * searchsorted_cuda_kernel.cu:84-142 (searchsorted_cuda_wrapper(a,v,res,side_left)).
+ * a (nrow_a,ncol_a) sorted rows, v (nrow_v,ncol_v); nrow_a==1 or nrow_v==1 broadcast.
+ * out (max(nrow_a,nrow_v), ncol_v) int64 = numpy.searchsorted(side). */
+int nerfmi_searchsorted(const float *a, const float *v, int nrow_a, int nrow_v, int ncol_a, int ncol_v,
+                        int side_left, int64_t *out, nerfmi_stream_t stream);
+
+/* ---- a4: merge -- models/rendering.py:247 --------------------------------
+ * out (n_rays, na+nb) = sort(cat[za, zb], -1) values. */
+int nerfmi_merge_sorted(const float *za, const float *zb, int n_rays, int na, int nb, float *out,
+                        nerfmi_stream_t stream);
+
+/* rendering.py:242-247 fused: z_mid -> sample_pdf(z_mid, w[:,1:-1]) -> sort(cat).
+ * z_coarse (n_rays,S), weights_coarse (n_rays,S), u NULL => det.
+ * z_fine_out (n_rays,S+F).  z_new_out optional (n_rays,F). */
+int nerfmi_importance_resample(const float *z_coarse, const float *weights_coarse, const float *u, int n_rays,
+                               int n_samples, int n_importance, float *z_new_out, float *z_fine_out,
+                               nerfmi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFMI_H */

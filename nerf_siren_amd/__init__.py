@@ -1,0 +1,21 @@
+"""nerf_siren_amd -- MI355X-native volumetric-rendering hot path of Freedomcls/nerf-siren.
+
+Public API mirrors the reference: render_rays, sample_pdf (models/rendering.py),
+Embedding, NeRF (models/nerf.py), searchsorted (torchsearchsorted).  All compute is
+in libnerfmi.so (hand-written HIP for gfx950) behind the C ABI of include/nerfmi.h.
+"""
+__version__ = "0.1.0"
+
+
+def __getattr__(name):
+    # torch-dependent modules load lazily so that `nerf_siren_amd.synth` stays numpy-only
+    if name in ("render_rays", "sample_pdf"):
+        from . import rendering
+        return getattr(rendering, name)
+    if name in ("Embedding", "NeRF"):
+        from . import nerf
+        return getattr(nerf, name)
+    if name == "searchsorted":
+        from . import ops
+        return ops.searchsorted
+    raise AttributeError(name)

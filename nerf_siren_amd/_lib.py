@@ -1,0 +1,71 @@
+"""ctypes binding of the C ABI in include/nerfmi.h (libnerfmi.so, gfx950).
+
+There is NO fallback: if the HIP library is missing or a call fails this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnerfmi.so")
+
+_f = C.c_void_p          # device pointers travel as integers
+_i = C.c_int
+_i64 = C.c_int64
+_fl = C.c_float
+
+SIGNATURES = {
+    "nerfmi_version": (C.c_int, []),
+    "nerfmi_last_error": (C.c_char_p, []),
+    "nerfmi_sample_stratified": (_i, [_f, _f, _i, _i, _i, _fl, _f, _f]),
+    "nerfmi_embed": (_i, [_f, _i64, _i, _f, _f]),
+    "nerfmi_nerf_packed_floats": (C.c_size_t, []),
+    "nerfmi_nerf_pack": (_i, [C.POINTER(C.c_void_p), _f, _f]),
+    "nerfmi_nerf_saved_floats": (C.c_size_t, [_i64]),
+    "nerfmi_nerf_forward_rays": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _f]),
+    "nerfmi_nerf_forward_embedded": (_i, [_f, _f, _i64, _i, _f, _f]),
+    "nerfmi_nerf_backward_workspace_floats": (C.c_size_t, [_i64]),
+    "nerfmi_nerf_backward_rays": (_i, [_f, _f, _f, _i, _i, _f, _f, C.POINTER(C.c_void_p), _f, _f]),
+    "nerfmi_composite": (_i, [_f, _i, _f, _f, _f, _fl, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "nerfmi_composite_backward": (_i, [_f, _f, _f, _f, _fl, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "nerfmi_sample_pdf": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _f, _f]),
+    "nerfmi_search_lerp": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _f]),
+    "nerfmi_searchsorted": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
+    "nerfmi_merge_sorted": (_i, [_f, _f, _i, _i, _i, _f, _f]),
+    "nerfmi_importance_resample": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _f]),
+}
+
+_lib = None
+
+
+class NerfmiError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "nerf_siren_amd has no CPU/PyTorch fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().nerfmi_last_error().decode("utf-8", "replace")
+        raise NerfmiError(f"{what or 'nerfmi'} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

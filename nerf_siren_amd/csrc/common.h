@@ -1,0 +1,75 @@
+// Shared helpers for the gfx950 kernels behind include/nerfmi.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/nerfmi.h"
+
+namespace nerfmi {
+
+void set_error(const char *fmt, ...);
+
+#define NERFMI_REQUIRE(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            nerfmi::set_error(__VA_ARGS__);       \
+            return NERFMI_E_INVALID;              \
+        }                                         \
+    } while (0)
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return NERFMI_E_LAUNCH;
+    }
+    return NERFMI_OK;
+}
+
+constexpr int WAVE = 64;
+
+// torch.linspace(0,1,n)[i] on CPU fp32: symmetric fill with one rounding
+// (fma form) -- oracle/nerf_oracle.py linspace01.
+__device__ __forceinline__ float linspace01(int i, int n) {
+    if (n <= 1) return 0.f;
+    const float step = __fdiv_rn(1.0f, (float)(n - 1));
+    return (i < n / 2) ? __fmul_rn(step, (float)i) : __builtin_fmaf(-step, (float)(n - 1 - i), 1.0f);
+}
+
+// ---- wave-level (64-lane) scans / reductions in fp64 -----------------------
+__device__ __forceinline__ double shfl_up_d(double v, int d) { return __shfl_up(v, d, WAVE); }
+__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, WAVE); }
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
+    return v;
+}
+
+// inclusive scans over the 64 lanes (Kogge-Stone)
+__device__ __forceinline__ double wave_incl_prod_d(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        double o = shfl_up_d(v, d);
+        if (lane >= d) v *= o;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_incl_sum_d(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        double o = shfl_up_d(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// ||d|| as restated in the oracle (ray_norm): fp32, x,y,z order, no fma.
+__device__ __forceinline__ float ray_norm(float dx, float dy, float dz) {
+    float s = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+    s = __fadd_rn(s, __fmul_rn(dz, dz));
+    return __fsqrt_rn(s);
+}
+
+}  // namespace nerfmi

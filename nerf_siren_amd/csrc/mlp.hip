@@ -1,0 +1,373 @@
+// Fused Embedding + NeRF MLP forward for gfx950 (MI355X), exact fp32 on the
+// matrix cores (v_mfma_f32_32x32x2_f32).  models/nerf.py:21-38, :83-124 and the
+// inference() head models/rendering.py:131-159.
+//
+// One wavefront owns 32 sample points and carries their whole 256-wide hidden
+// state through all ten layers IN REGISTERS (8 blocks x 16 accumulator VGPRs);
+// see mlp_layout.h for why a layer's accumulators are directly the next layer's
+// B operand.  Weights stream from L2 (2.4 MB per model, L2-resident) as
+// pre-packed, fully coalesced 1 KiB fragments through a small register ring; no
+// LDS, no barrier: the four waves of a workgroup are independent and each SIMD
+// runs one wave that issues MFMAs back to back.
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace nerfmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__constant__ LayerDesc d_layers[NL_FWD] = {
+    LAYERS[0], LAYERS[1], LAYERS[2], LAYERS[3], LAYERS[4], LAYERS[5], LAYERS[6], LAYERS[7], LAYERS[8], LAYERS[9]};
+
+struct ParamPtrs {
+    const float *p[N_PARAMS];
+};
+struct GradPtrs {
+    float *p[N_PARAMS];
+};
+
+// ---------------------------------------------------------------------------
+// pack: state_dict tensors -> fragment-order images (mlp_layout.h)
+// ---------------------------------------------------------------------------
+__global__ void pack_kernel(ParamPtrs P, float *__restrict__ packed) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < PACKED_FLOATS; idx += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (idx < OFF_SMALL) {
+            int li = 0;
+#pragma unroll
+            for (int l = 1; l < NL_FWD; ++l)
+                if (idx >= d_layers[l].off) li = l;
+            const LayerDesc L = d_layers[li];
+            const int rel = idx - L.off;
+            const int t = rel & 3, lane = (rel >> 2) & 63, g = rel >> 8;
+            const int q = g & 3, kb = (g >> 2) % L.KB, jb = (g >> 2) / L.KB;
+            const int row = 32 * jb + (lane & 31);
+            const int kc = 32 * kb + 8 * q + 4 * (lane >> 5) + t;
+            const int p0 = pad32(L.seg0);
+            int col = -1;
+            if (kc < p0) { if (kc < L.seg0) col = kc; }
+            else if (kc - p0 < L.seg1) col = L.seg0 + (kc - p0);
+            if (col >= 0 && row < L.out_f) v = P.p[L.param][row * L.in_f + col];
+        } else if (idx < OFF_TRANS) {
+            const int s = idx - OFF_SMALL;
+            if (s < 8 * 256) v = P.p[2 * (s >> 8) + 1][s & 255];
+            else if (idx < OFF_BIAS_DIR) v = P.p[17][idx - OFF_BIAS_FINAL];
+            else if (idx < OFF_W_SIGMA) v = P.p[19][idx - OFF_BIAS_DIR];
+            else if (idx < OFF_B_SIGMA) v = P.p[PARAM_SIGMA_W][idx - OFF_W_SIGMA];
+            else if (idx < OFF_W_RGB) v = (idx == OFF_B_SIGMA) ? P.p[PARAM_SIGMA_B][0] : 0.f;
+            else if (idx < OFF_B_RGB) v = P.p[PARAM_RGB_W][idx - OFF_W_RGB];
+            else v = (idx - OFF_B_RGB < 3) ? P.p[PARAM_RGB_B][idx - OFF_B_RGB] : 0.f;
+        } else {
+            int li = 1;
+#pragma unroll
+            for (int l = 2; l < NL_FWD; ++l)
+                if (idx >= d_layers[l].t_off) li = l;
+            const LayerDesc L = d_layers[li];
+            const int JBc = L.JB;                       // contraction blocks = output blocks of W
+            const int rel = idx - L.t_off;
+            const int t = rel & 3, lane = (rel >> 2) & 63, g = rel >> 8;
+            const int q = g & 3, jb = (g >> 2) % JBc, kbo = (g >> 2) / JBc;
+            const int row = 32 * jb + 8 * q + 4 * (lane >> 5) + t;       // W row (output unit)
+            const int col = L.t_col0 + 32 * kbo + (lane & 31);           // W col (input unit)
+            if (row < L.out_f && col < L.in_f) v = P.p[L.param][row * L.in_f + col];
+        }
+        packed[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// one dense layer on the matrix cores
+// ---------------------------------------------------------------------------
+constexpr int PF = 6;  // weight-fragment groups in flight per wave (1 KiB each)
+
+__device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+// acc[jb] = bias + W[jb-block rows] . [in0 ; in1]     (JB x (KB0+KB1) blocks)
+// wp: this layer's packed image + lane*4;  bias: natural order + 4*half
+template <int KB0, int KB1, int JB>
+__device__ __forceinline__ void layer_mfma(const float *__restrict__ wp, const float *__restrict__ bias,
+                                           const f32x16 *in0, const f32x16 *in1, f32x16 *acc) {
+    constexpr int KBT = KB0 + KB1;
+    constexpr int G = JB * KBT * 4;
+    f32x4 ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = ldg4(wp + i * 256);
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+        f32x16 c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = ldg4(bias + 32 * jb + 8 * q);
+            c[4 * q + 0] = b[0]; c[4 * q + 1] = b[1]; c[4 * q + 2] = b[2]; c[4 * q + 3] = b[3];
+        }
+#pragma unroll
+        for (int kb = 0; kb < KBT; ++kb) {
+            const f32x16 B = (kb < KB0) ? in0[kb] : in1[kb - KB0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                constexpr int dummy = 0; (void)dummy;
+                const int g = (jb * KBT + kb) * 4 + q;
+                const f32x4 a = ring[g % PF];
+                if (g + PF < G) ring[g % PF] = ldg4(wp + (g + PF) * 256);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], B[4 * q + 0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], B[4 * q + 1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], B[4 * q + 2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], B[4 * q + 3], c, 0, 0, 0);
+            }
+        }
+        acc[jb] = c;
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void relu_copy(f32x16 *dst, const f32x16 *src) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[b][r] = fmaxf(src[b][r], 0.f);
+}
+
+// store NB blocks as [row][point]: row = row0 + 32*b + 8*(r>>2) + 4*half + (r&3)
+template <int NB>
+__device__ __forceinline__ void save_blocks(float *__restrict__ saved, int64_t ld, int row0, int half, int64_t p,
+                                            bool ok, const f32x16 *v) {
+    if (!ok) return;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            saved[(int64_t)(row0 + 32 * b + 8 * (r >> 2) + 4 * half + (r & 3)) * ld + p] = v[b][r];
+}
+
+// dot of the lane's share of a [NB x 16] block set with a natural-order vector
+template <int NB>
+__device__ __forceinline__ float dot_blocks(const f32x16 *v, const float *__restrict__ w_half) {
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w = ldg4(w_half + 32 * b + 8 * q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s = __builtin_fmaf(w[t], v[b][4 * q + t], s);
+        }
+    return s + __shfl_xor(s, 32, WAVE);
+}
+
+// Embedding(3,10) of this lane's point, as the two B-operand blocks of layer 1
+__device__ __forceinline__ void embed_xyz_blocks(float x, float y, float z, int half, f32x16 *e) {
+    float v[64];
+    v[0] = x; v[1] = y; v[2] = z; v[63] = 0.f;
+    const float xyz[3] = {x, y, z};
+#pragma unroll
+    for (int f = 0; f < 10; ++f)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float s, c;
+            sincosf(__fmul_rn(xyz[d], (float)(1 << f)), &s, &c);
+            v[3 + 6 * f + d] = s;
+            v[3 + 6 * f + 3 + d] = c;
+        }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c0 = 32 * kb + 8 * (r >> 2) + (r & 3);
+            e[kb][r] = half ? v[c0 + 4] : v[c0];
+        }
+}
+
+// Embedding(3,4) of the ray direction, one block (channels 27..31 = 0)
+__device__ __forceinline__ void embed_dir_block(float x, float y, float z, int half, f32x16 &e) {
+    float v[32];
+    v[0] = x; v[1] = y; v[2] = z;
+#pragma unroll
+    for (int c = 27; c < 32; ++c) v[c] = 0.f;
+    const float xyz[3] = {x, y, z};
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float s, c;
+            sincosf(__fmul_rn(xyz[d], (float)(1 << f)), &s, &c);
+            v[3 + 6 * f + d] = s;
+            v[3 + 6 * f + 3 + d] = c;
+        }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c0 = 8 * (r >> 2) + (r & 3);
+        e[r] = half ? v[c0 + 4] : v[c0];
+    }
+}
+
+template <bool EMBEDDED, bool SIGMA_ONLY, bool SAVE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ rays, const float *__restrict__ z,
+                    const float *__restrict__ xemb, int64_t n_points, int n_per_ray, float *__restrict__ out,
+                    float *__restrict__ saved, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t p0 = wave * 32;
+    if (p0 >= n_points) return;
+    const int64_t praw = p0 + (lane & 31);
+    const bool ok = praw < n_points;
+    const int64_t p = ok ? praw : n_points - 1;
+
+    f32x16 e[2], de[1];
+    if (EMBEDDED) {
+        const int ldx = SIGMA_ONLY ? 63 : 90;
+        const float *xr = xemb + p * ldx;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = 32 * kb + 8 * (r >> 2) + 4 * half + (r & 3);
+                e[kb][r] = (c < 63) ? xr[c] : 0.f;
+            }
+        if (!SIGMA_ONLY) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = 8 * (r >> 2) + 4 * half + (r & 3);
+                de[0][r] = (c < 27) ? xr[63 + c] : 0.f;
+            }
+        }
+    } else {
+        const int64_t ray = p / n_per_ray;
+        const float *rr = rays + ray * 8;
+        const float zz = z[p];
+        // rendering.py:224-225  xyz = o + d*z  (two roundings, as torch)
+        const float x = __fadd_rn(rr[0], __fmul_rn(rr[3], zz));
+        const float y = __fadd_rn(rr[1], __fmul_rn(rr[4], zz));
+        const float w = __fadd_rn(rr[2], __fmul_rn(rr[5], zz));
+        embed_xyz_blocks(x, y, w, half, e);
+        if (!SIGMA_ONLY) embed_dir_block(rr[3], rr[4], rr[5], half, de[0]);
+    }
+    if (SAVE) {
+        save_blocks<2>(saved, ld, S_EMB, half, p, ok, e);
+        if (!SIGMA_ONLY) save_blocks<1>(saved, ld, S_DEMB, half, p, ok, de);
+    }
+
+    const float *wl = packed + lane * 4;
+    const float *bias = packed + OFF_BIAS + 4 * half;
+    f32x16 h[8], acc[8];
+
+    layer_mfma<2, 0, 8>(wl + OFF_L1, bias, e, nullptr, acc);
+    relu_copy<8>(h, acc);
+    if (SAVE) save_blocks<8>(saved, ld, S_H, half, p, ok, h);
+    for (int l = 1; l <= 3; ++l) {
+        layer_mfma<8, 0, 8>(wl + OFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc);
+        relu_copy<8>(h, acc);
+        if (SAVE) save_blocks<8>(saved, ld, S_H + 256 * l, half, p, ok, h);
+    }
+    layer_mfma<2, 8, 8>(wl + OFF_L5, bias + 256 * 4, e, h, acc);
+    relu_copy<8>(h, acc);
+    if (SAVE) save_blocks<8>(saved, ld, S_H + 256 * 4, half, p, ok, h);
+
+    float sigma = 0.f;
+    for (int l = 5; l <= 8; ++l) {   // xyz_encoding_6..8, then xyz_encoding_final (no ReLU)
+        if (l == 8) {
+            sigma = dot_blocks<8>(h, packed + OFF_W_SIGMA + 4 * half) + packed[OFF_B_SIGMA];
+            if (SIGMA_ONLY) break;
+        }
+        layer_mfma<8, 0, 8>(wl + OFF_L6 + (l - 5) * SZ_HID, bias + 256 * l, h, nullptr, acc);
+        if (l < 8) {
+            relu_copy<8>(h, acc);
+            if (SAVE) save_blocks<8>(saved, ld, S_H + 256 * l, half, p, ok, h);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) h[b] = acc[b];
+            if (SAVE) save_blocks<8>(saved, ld, S_FINAL, half, p, ok, h);
+        }
+    }
+    if (SIGMA_ONLY) {
+        if (ok && half == 0) out[p] = sigma;
+        return;
+    }
+    f32x16 dh[4];
+    layer_mfma<8, 1, 4>(wl + OFF_DIR, packed + OFF_BIAS_DIR + 4 * half, h, de, acc);
+    relu_copy<4>(dh, acc);
+    if (SAVE) save_blocks<4>(saved, ld, S_DIRH, half, p, ok, dh);
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float pre = dot_blocks<4>(dh, packed + OFF_W_RGB + 128 * c + 4 * half) + packed[OFF_B_RGB + c];
+        rgb[c] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-pre)));
+    }
+    if (ok && half == 0) {
+        float4 o;
+        o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2]; o.w = sigma;
+        reinterpret_cast<float4 *>(out)[p] = o;
+        if (SAVE) {
+            saved[(int64_t)(S_RGB + 0) * ld + p] = rgb[0];
+            saved[(int64_t)(S_RGB + 1) * ld + p] = rgb[1];
+            saved[(int64_t)(S_RGB + 2) * ld + p] = rgb[2];
+        }
+    }
+}
+
+static inline int64_t pad_points(int64_t n) { return (n + 31) / 32 * 32; }
+
+}  // namespace nerfmi
+
+using namespace nerfmi;
+
+extern "C" {
+
+size_t nerfmi_nerf_packed_floats(void) { return (size_t)PACKED_FLOATS; }
+
+int nerfmi_nerf_pack(const float *const *params, float *packed, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(params && packed, "nerf_pack: null pointer");
+    ParamPtrs P;
+    for (int i = 0; i < N_PARAMS; ++i) {
+        NERFMI_REQUIRE(params[i], "nerf_pack: params[%d] is null", i);
+        P.p[i] = params[i];
+    }
+    hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, P, packed);
+    return check_launch("nerf_pack");
+}
+
+size_t nerfmi_nerf_saved_floats(int64_t n_points) { return (size_t)SAVED_ROWS * (size_t)pad_points(n_points); }
+
+int nerfmi_nerf_forward_rays(const float *packed, const float *rays, const float *z, int n_rays, int n_per_ray,
+                             int sigma_only, float *out, float *saved, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1, "nerf_forward_rays: bad sizes");
+    const int64_t n_points = (int64_t)n_rays * n_per_ray;
+    if (n_points == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(packed && rays && z && out, "nerf_forward_rays: null pointer");
+    NERFMI_REQUIRE(!(saved && sigma_only), "nerf_forward_rays: saved activations need the full (rgb,sigma) pass");
+    const int64_t waves = (n_points + 31) / 32;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    const int64_t ld = pad_points(n_points);
+    hipStream_t st = (hipStream_t)stream;
+    if (sigma_only)
+        hipLaunchKernelGGL((nerf_forward_kernel<false, true, false>), grid, block, 0, st, packed, rays, z, nullptr,
+                           n_points, n_per_ray, out, nullptr, ld);
+    else if (saved)
+        hipLaunchKernelGGL((nerf_forward_kernel<false, false, true>), grid, block, 0, st, packed, rays, z, nullptr,
+                           n_points, n_per_ray, out, saved, ld);
+    else
+        hipLaunchKernelGGL((nerf_forward_kernel<false, false, false>), grid, block, 0, st, packed, rays, z, nullptr,
+                           n_points, n_per_ray, out, nullptr, ld);
+    return check_launch("nerf_forward_rays");
+}
+
+int nerfmi_nerf_forward_embedded(const float *packed, const float *x, int64_t n, int sigma_only, float *out,
+                                 nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n >= 0, "nerf_forward_embedded: bad size");
+    if (n == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(packed && x && out, "nerf_forward_embedded: null pointer");
+    const int64_t waves = (n + 31) / 32;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (sigma_only)
+        hipLaunchKernelGGL((nerf_forward_kernel<true, true, false>), grid, block, 0, st, packed, nullptr, nullptr, x, n,
+                           1, out, nullptr, (int64_t)0);
+    else
+        hipLaunchKernelGGL((nerf_forward_kernel<true, false, false>), grid, block, 0, st, packed, nullptr, nullptr, x,
+                           n, 1, out, nullptr, (int64_t)0);
+    return check_launch("nerf_forward_embedded");
+}
+
+}  // extern "C"

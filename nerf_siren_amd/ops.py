@@ -1,0 +1,250 @@
+"""Tensor-level wrappers over the C ABI (include/nerfmi.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; all
+compute happens in libnerfmi.so.  Every op requires contiguous fp32 tensors on
+a ROCm device and raises otherwise -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _req(t: torch.Tensor, name: str, shape=None, dtype=torch.float32):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: nerf_siren_amd runs on the GPU only (tensor is on {t.device}); "
+                           "there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if shape is not None:
+        if t.dim() != len(shape) or any(s is not None and s != d for s, d in zip(shape, t.shape)):
+            raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t
+
+
+def version() -> int:
+    return _lib.lib().nerfmi_version()
+
+
+# --------------------------------------------------------------------------- a2
+def sample_stratified(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand=None):
+    rays = _req(rays, "rays", (None, 8))
+    n = rays.shape[0]
+    if perturb > 0:
+        perturb_rand = _req(perturb_rand, "perturb_rand", (n, n_samples))
+        if perturb_rand is None:
+            raise ValueError("perturb > 0 needs perturb_rand")
+    z = torch.empty((n, n_samples), device=rays.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_sample_stratified(ptr(rays), ptr(perturb_rand) if perturb > 0 else None, n, n_samples,
+                                              int(bool(use_disp)), float(perturb), ptr(z), _stream(rays)),
+          "sample_stratified")
+    return z
+
+
+# --------------------------------------------------------------------------- a5
+def embed(x, n_freqs):
+    x = _req(x, "x", (None, 3))
+    out = torch.empty((x.shape[0], 3 * (2 * n_freqs + 1)), device=x.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_embed(ptr(x), x.shape[0], n_freqs, ptr(out), _stream(x)), "embed")
+    return out
+
+
+# --------------------------------------------------------------------------- a6
+PARAM_ORDER = ([f"xyz_encoding_{i}.0.{k}" for i in range(1, 9) for k in ("weight", "bias")]
+               + ["xyz_encoding_final.weight", "xyz_encoding_final.bias", "dir_encoding.0.weight",
+                  "dir_encoding.0.bias", "sigma.weight", "sigma.bias", "rgb.0.weight", "rgb.0.bias"])
+PARAM_SHAPES = ([(256, 63), (256,)] + [(256, 256), (256,)] * 3 + [(256, 319), (256,)] + [(256, 256), (256,)] * 3
+                + [(256, 256), (256,), (128, 283), (128,), (1, 256), (1,), (3, 128), (3,)])
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def nerf_pack(params, out=None):
+    """params: the 24 tensors in PARAM_ORDER -> packed fragment-order blob."""
+    ps = []
+    for name, shape, t in zip(PARAM_ORDER, PARAM_SHAPES, params):
+        ps.append(_req(t.detach(), name, shape))
+    n = _lib.lib().nerfmi_nerf_packed_floats()
+    if out is None:
+        out = torch.empty(n, device=ps[0].device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_nerf_pack(_ptr_array(ps), ptr(out), _stream(out)), "nerf_pack")
+    return out
+
+
+def nerf_saved_floats(n_points):
+    return _lib.lib().nerfmi_nerf_saved_floats(n_points)
+
+
+def nerf_forward_rays(packed, rays, z, sigma_only=False, save=False):
+    rays = _req(rays, "rays", (None, 8))
+    z = _req(z, "z", (rays.shape[0], None))
+    packed = _req(packed, "packed", (_lib.lib().nerfmi_nerf_packed_floats(),))
+    n, p = z.shape
+    out = torch.empty((n * p, 1 if sigma_only else 4), device=rays.device, dtype=torch.float32)
+    saved = None
+    if save:
+        saved = torch.empty(nerf_saved_floats(n * p), device=rays.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_nerf_forward_rays(ptr(packed), ptr(rays), ptr(z), n, p, int(bool(sigma_only)), ptr(out),
+                                              ptr(saved), _stream(rays)), "nerf_forward_rays")
+    return (out, saved) if save else out
+
+
+def nerf_forward_embedded(packed, x, sigma_only=False):
+    x = _req(x, "x", (None, 63 if sigma_only else 90))
+    packed = _req(packed, "packed", (_lib.lib().nerfmi_nerf_packed_floats(),))
+    out = torch.empty((x.shape[0], 1 if sigma_only else 4), device=x.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_nerf_forward_embedded(ptr(packed), ptr(x), x.shape[0], int(bool(sigma_only)), ptr(out),
+                                                  _stream(x)), "nerf_forward_embedded")
+    return out
+
+
+def nerf_backward_rays(packed, rays, z, saved, grad_out, grads=None):
+    """-> list of 24 gradient tensors (PARAM_ORDER), written not accumulated."""
+    rays = _req(rays, "rays", (None, 8))
+    z = _req(z, "z", (rays.shape[0], None))
+    n, p = z.shape
+    grad_out = _req(grad_out, "grad_out", (n * p, 4))
+    if grads is None:
+        grads = [torch.empty(s, device=rays.device, dtype=torch.float32) for s in PARAM_SHAPES]
+    ws = torch.empty(_lib.lib().nerfmi_nerf_backward_workspace_floats(n * p), device=rays.device,
+                     dtype=torch.float32)
+    check(_lib.lib().nerfmi_nerf_backward_rays(ptr(packed), ptr(rays), ptr(z), n, p, ptr(saved), ptr(grad_out),
+                                               _ptr_array(grads), ptr(ws), _stream(rays)), "nerf_backward_rays")
+    return grads
+
+
+# --------------------------------------------------------------------------- a8
+def composite(field, z, rays, noise=None, noise_std=0.0, white_back=False, sigma_only=False, want_weights=True):
+    rays = _req(rays, "rays", (None, 8))
+    n = rays.shape[0]
+    z = _req(z, "z", (n, None))
+    p = z.shape[1]
+    field = _req(field.reshape(n, p) if sigma_only else field.reshape(n, p, 4), "field")
+    noise = _req(noise, "noise", (n, p)) if (noise is not None and noise_std != 0) else None
+    dev = rays.device
+    weights = torch.empty((n, p), device=dev, dtype=torch.float32) if want_weights else None
+    opacity = torch.empty((n,), device=dev, dtype=torch.float32)
+    rgb = depth = None
+    if not sigma_only:
+        rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        depth = torch.empty((n,), device=dev, dtype=torch.float32)
+    check(_lib.lib().nerfmi_composite(ptr(field), int(bool(sigma_only)), ptr(z), ptr(rays), ptr(noise),
+                                      float(noise_std), n, p, int(bool(white_back)), ptr(weights), ptr(rgb),
+                                      ptr(depth), ptr(opacity), _stream(rays)), "composite")
+    return weights, rgb, depth, opacity
+
+
+def composite_backward(field, z, rays, noise, noise_std, white_back, g_rgb, g_depth, g_opacity):
+    rays = _req(rays, "rays", (None, 8))
+    n = rays.shape[0]
+    z = _req(z, "z", (n, None))
+    p = z.shape[1]
+    field = _req(field.reshape(n, p, 4), "field")
+    noise = _req(noise, "noise", (n, p)) if (noise is not None and noise_std != 0) else None
+    g_rgb = _req(g_rgb, "g_rgb", (n, 3))
+    g_depth = _req(g_depth, "g_depth", (n,))
+    g_opacity = _req(g_opacity, "g_opacity", (n,))
+    grad_field = torch.empty((n * p, 4), device=rays.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_composite_backward(ptr(field), ptr(z), ptr(rays), ptr(noise), float(noise_std), n, p,
+                                               int(bool(white_back)), ptr(g_rgb), ptr(g_depth), ptr(g_opacity),
+                                               ptr(grad_field), _stream(rays)), "composite_backward")
+    return grad_field
+
+
+# --------------------------------------------------------------------------- a3 / a4
+def sample_pdf(bins, weights, n_importance, det=False, u=None, return_aux=False):
+    """sample_pdf(bins, weights, N_importance, det) of models/rendering.py:22-67.
+    u: the torch.rand(N, N_importance) draw when not det (required then)."""
+    weights = _req(weights, "weights", (None, None))
+    n, nw = weights.shape
+    bins = _req(bins, "bins", (n, nw + 1))
+    if not det:
+        if u is None:
+            u = torch.rand((n, n_importance), device=bins.device, dtype=torch.float32)
+        u = _req(u, "u", (n, n_importance))
+    else:
+        u = None
+    dev = bins.device
+    samples = torch.empty((n, n_importance), device=dev, dtype=torch.float32)
+    cdf = torch.empty((n, nw + 1), device=dev, dtype=torch.float32) if return_aux else None
+    inds = torch.empty((n, n_importance), device=dev, dtype=torch.int64) if return_aux else None
+    check(_lib.lib().nerfmi_sample_pdf(ptr(bins), ptr(weights), ptr(u), n, nw, n_importance, ptr(cdf), ptr(inds),
+                                       ptr(samples), _stream(bins)), "sample_pdf")
+    return (samples, cdf, inds) if return_aux else samples
+
+
+def search_lerp(bins, cdf, u):
+    cdf = _req(cdf, "cdf", (None, None))
+    n, nb = cdf.shape
+    bins = _req(bins, "bins", (n, nb))
+    u = _req(u, "u", (n, None))
+    f = u.shape[1]
+    samples = torch.empty((n, f), device=cdf.device, dtype=torch.float32)
+    inds = torch.empty((n, f), device=cdf.device, dtype=torch.int64)
+    check(_lib.lib().nerfmi_search_lerp(ptr(bins), ptr(cdf), ptr(u), n, nb - 1, f, ptr(inds), ptr(samples),
+                                        _stream(cdf)), "search_lerp")
+    return inds, samples
+
+
+def searchsorted(a, v, out=None, side="left"):
+    """torchsearchsorted.searchsorted(a, v, out=None, side='left')
+    (torchsearchsorted/src/torchsearchsorted/searchsorted.py:20-53)."""
+    assert len(a.shape) == 2, "input `a` must be 2-D."
+    assert len(v.shape) == 2, "input `v` mus(t) be 2-D."
+    assert (a.shape[0] == v.shape[0] or a.shape[0] == 1 or v.shape[0] == 1), \
+        "`a` and `v` must have the same number of rows or one of them must have only 1 row"
+    assert a.device == v.device, "`a` and `v` must be on the same device"
+    if side not in ("left", "right"):
+        raise ValueError("side must be 'left' or 'right'")
+    a = _req(a, "a")
+    v = _req(v, "v")
+    nrow = max(a.shape[0], v.shape[0])
+    if out is None:
+        out = torch.empty((nrow, v.shape[1]), device=v.device, dtype=torch.long)
+    else:
+        assert out.device == v.device and out.dtype == torch.long and tuple(out.shape) == (nrow, v.shape[1])
+        assert out.is_contiguous()
+    check(_lib.lib().nerfmi_searchsorted(ptr(a), ptr(v), a.shape[0], v.shape[0], a.shape[1], v.shape[1],
+                                         int(side == "left"), ptr(out), _stream(v)), "searchsorted")
+    return out
+
+
+def merge_sorted(za, zb):
+    za = _req(za, "za", (None, None))
+    zb = _req(zb, "zb", (za.shape[0], None))
+    n = za.shape[0]
+    out = torch.empty((n, za.shape[1] + zb.shape[1]), device=za.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_merge_sorted(ptr(za), ptr(zb), n, za.shape[1], zb.shape[1], ptr(out), _stream(za)),
+          "merge_sorted")
+    return out
+
+
+def importance_resample(z_coarse, weights_coarse, n_importance, u=None, want_new=False):
+    z_coarse = _req(z_coarse, "z_coarse", (None, None))
+    n, s = z_coarse.shape
+    weights_coarse = _req(weights_coarse, "weights_coarse", (n, s))
+    u = _req(u, "u", (n, n_importance))
+    z_fine = torch.empty((n, s + n_importance), device=z_coarse.device, dtype=torch.float32)
+    z_new = torch.empty((n, n_importance), device=z_coarse.device, dtype=torch.float32) if want_new else None
+    check(_lib.lib().nerfmi_importance_resample(ptr(z_coarse), ptr(weights_coarse), ptr(u), n, s, n_importance,
+                                                ptr(z_new), ptr(z_fine), _stream(z_coarse)), "importance_resample")
+    return (z_fine, z_new) if want_new else z_fine

@@ -1,0 +1,135 @@
+"""render_rays() -- the reference's renderer API (models/rendering.py:70-262)
+on the MI355X-native kernels.
+
+Call sequence per batch of N rays (one HIP stream, no host sync):
+  sample_stratified -> nerf_forward_rays(coarse) -> composite
+  -> importance_resample (z_mid, cdf scan, searchsorted, lerp, merge-sort)
+  -> nerf_forward_rays(fine) -> composite
+Training (grad enabled): each field pass is one autograd node whose backward is
+composite_backward -> nerf_backward_rays; no gradient crosses sample_pdf
+(rendering.py:54 cdf.detach(), :244 .detach()).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+__all__ = ["render_rays", "sample_pdf"]
+
+
+def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, u=None):
+    """models/rendering.py:22-67.  `u` optionally injects the torch.rand draw."""
+    if eps != 1e-5:
+        raise NotImplementedError("eps is fixed to the reference's 1e-5")
+    return ops.sample_pdf(bins, weights, N_importance, det=det, u=u)
+
+
+class FieldRender(torch.autograd.Function):
+    """inference() of rendering.py:105-190 for the full (rgb, sigma) branch:
+    (rays, z) -> rgb, depth, opacity, weights; gradients to the 24 parameters."""
+
+    @staticmethod
+    def forward(ctx, model, rays, z, noise, noise_std, white_back, *params):
+        packed = model.packed()
+        field, saved = ops.nerf_forward_rays(packed, rays, z, sigma_only=False, save=True)
+        weights, rgb, depth, opacity = ops.composite(field, z, rays, noise, noise_std, white_back)
+        ctx.save_for_backward(rays, z, noise if noise is not None else rays.new_empty(0), field, saved, packed)
+        ctx.cfg = (noise is not None, float(noise_std), bool(white_back))
+        ctx.mark_non_differentiable(weights)
+        return rgb, depth, opacity, weights
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_opacity, _g_w):
+        rays, z, noise, field, saved, packed = ctx.saved_tensors
+        has_noise, noise_std, white_back = ctx.cfg
+        n = rays.shape[0]
+        g_rgb = g_rgb if g_rgb is not None else rays.new_zeros((n, 3))
+        g_depth = g_depth if g_depth is not None else rays.new_zeros((n,))
+        g_opacity = g_opacity if g_opacity is not None else rays.new_zeros((n,))
+        grad_field = ops.composite_backward(field, z, rays, noise if has_noise else None, noise_std, white_back,
+                                            g_rgb.contiguous(), g_depth.contiguous(), g_opacity.contiguous())
+        grads = ops.nerf_backward_rays(packed, rays, z, saved, grad_field)
+        return (None, None, None, None, None, None, *grads)
+
+
+class EmbeddedField(torch.autograd.Function):
+    """NeRF.forward(x, sigma_only) with autograd (module-level API)."""
+
+    @staticmethod
+    def forward(ctx, model, x, sigma_only, *params):
+        raise NotImplementedError("training through NeRF.forward(x) on pre-embedded inputs is not wired yet; "
+                                  "train through render_rays() (the reference's only training path, "
+                                  "system.py:199-223) or call under torch.no_grad()")
+
+
+def _rng(rng, key, shape, device, kind):
+    t = None if rng is None else rng.get(key)
+    if t is not None:
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"rng['{key}'] has shape {tuple(t.shape)}, expected {tuple(shape)}")
+        return t
+    gen = torch.rand if kind == "rand" else torch.randn
+    return gen(shape, device=device, dtype=torch.float32)
+
+
+def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=0, noise_std=1, N_importance=0,
+                chunk=1024 * 32, white_back=False, test_time=False, _cls_num=6, network=None, *, rng=None):
+    """Same positional signature and result dict as models/rendering.py:70-83, :262.
+
+    models: [coarse] or [coarse, fine] nerf_siren_amd.NeRF; embeddings: [Embedding(3,10),
+    Embedding(3,4)] (their frequencies are compiled into the fused kernel; the
+    list is validated, not called).  rays (N,8) = [o, d, near, far] on the GPU.
+    chunk: accepted for compatibility; the fused kernels need no point chunking.
+    rng (keyword-only, optional): dict of injected random draws in the reference's
+    order -- 'perturb_rand' (N,S) [rendering.py:221], 'noise_coarse' (N,S) [:170],
+    'u' (N,F) [:47], 'noise_fine' (N,S+F); missing entries are drawn on the device.
+    """
+    if len(embeddings) != 2 or getattr(embeddings[0], "N_freqs", None) != 10 or \
+            getattr(embeddings[1], "N_freqs", None) != 4:
+        raise NotImplementedError("render_rays is compiled for Embedding(3,10) / Embedding(3,4) (system.py:181-182)")
+    if rays.dim() != 2 or rays.shape[1] != 8:
+        raise ValueError(f"rays must be (N_rays, 8), got {tuple(rays.shape)}")
+    rays = rays.detach().contiguous().float()
+    N = rays.shape[0]
+    dev = rays.device
+    S, F = int(N_samples), int(N_importance)
+    model_coarse = models[0]
+    train = torch.is_grad_enabled() and any(p.requires_grad for m in models for p in m.parameters())
+
+    pr = _rng(rng, "perturb_rand", (N, S), dev, "rand") if perturb > 0 else None
+    z = ops.sample_stratified(rays, S, use_disp, float(perturb), pr)
+
+    def noise_for(key, P):
+        # rendering.py:170 draws randn even when noise_std == 0 (result x0); the
+        # native path skips the draw -- identical outputs.
+        return _rng(rng, key, (N, P), dev, "randn") if noise_std != 0 else None
+
+    def full_pass(model, zz, key):
+        noise = noise_for(key, zz.shape[1])
+        if train:
+            rgb, depth, opacity, weights = FieldRender.apply(model, rays, zz, noise, float(noise_std),
+                                                            bool(white_back), *model.param_list())
+        else:
+            field = ops.nerf_forward_rays(model.packed(), rays, zz, sigma_only=False)
+            weights, rgb, depth, opacity = ops.composite(field, zz, rays, noise, noise_std, white_back)
+        return rgb, depth, opacity, weights
+
+    if test_time:
+        # weights_only branch (rendering.py:227-231): sigma-only coarse MLP
+        sig = ops.nerf_forward_rays(model_coarse.packed(), rays, z, sigma_only=True)
+        weights_coarse, _, _, op = ops.composite(sig, z, rays, noise_for("noise_coarse", S), noise_std, white_back,
+                                                 sigma_only=True)
+        result = {"opacity_coarse": op}
+    else:
+        rgb, depth, op, weights_coarse = full_pass(model_coarse, z, "noise_coarse")
+        result = {"rgb_coarse": rgb, "depth_coarse": depth, "opacity_coarse": op}
+
+    if F > 0:
+        u = _rng(rng, "u", (N, F), dev, "rand") if perturb != 0 else None     # det = (perturb == 0), :243
+        z_fine = ops.importance_resample(z, weights_coarse, F, u)
+        rgb, depth, op, _ = full_pass(models[1], z_fine, "noise_fine")
+        result["rgb_fine"] = rgb
+        result["depth_fine"] = depth
+        result["opacity_fine"] = op
+    return result
