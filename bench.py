@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Headline benchmark: ray-samples/s of render_rays() on Blender-lego-like rays
+(400x400 pinhole, N_samples=64 + N_importance=64), BASELINE.json configs[1]
+(batch 1024 rays per GPU), synthetic rays and seeded random-init weights.
+
+One "step" = one pass of the hot path over one batch of 1024 rays per rank:
+  --mode train (default): render_rays forward (coarse+fine, perturb=1,
+      noise_std=1) + MSE(coarse)+MSE(fine) + backward through both MLPs +
+      gradient all-reduce (RCCL, N>1) + Adam step  -- system.py:257-275
+  --mode infer: render_rays(test_time=True, perturb=0, noise_std=0) under
+      no_grad -- eval.py:85-96
+A ray-sample = one field evaluation: 64 coarse + 128 fine = 192 per ray.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fine
+NeRF MLP forward, fp32 MFMA bound): algorithmic FLOPs per launch / its average
+duration measured with HIP events on the launch stream inside the timed region.
+`cpu_baseline` is the numpy oracle timed on this box's host cores on a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_FULL = 1_186_816        # NeRF full forward per sample
+FLOP_SIGMA = 982_528         # sigma-only forward per sample
+FLOP_TRAIN = 3_489_024       # fwd + dW + dX per sample
+PEAK_F32_MFMA = 157.3        # TFLOP/s dense (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--batch", type=int, default=1024, help="rays per rank per step (configs[1])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(mode, n_rays):
+    """numpy oracle (kind 'port') on the host cores, bounded sample."""
+    import numpy as np
+    from nerf_siren_amd import synth
+    from oracle import nerf_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    params = [synth.nerf_params(1, False), synth.nerf_params(2, False)]
+    rays = synth.blender_rays(n_rays, seed=123)
+    t0 = time.perf_counter()
+    if mode == "infer":
+        O.render_rays(params, rays, 64, False, 0.0, 0.0, 64, True, True)
+    else:
+        rng = {"perturb_rand": synth.hash_uniform((n_rays, 64), 1), "noise_coarse": synth.hash_normal((n_rays, 64), 2),
+               "u": synth.hash_uniform((n_rays, 64), 3), "noise_fine": synth.hash_normal((n_rays, 128), 4)}
+        res = O.render_rays(params, rays, 64, False, 1.0, 1.0, 64, True, False, rng=rng, keep=True)
+        tgt = synth.hash_uniform((n_rays, 3), 5)
+        g = {"rgb_coarse": 2 * (res["rgb_coarse"] - tgt) / (3 * n_rays),
+             "rgb_fine": 2 * (res["rgb_fine"] - tgt) / (3 * n_rays)}
+        O.render_rays_backward(params, res, g, True)
+    dt = time.perf_counter() - t0
+    return {"value": n_rays * 192 / dt, "unit": "ray-samples/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n_rays} rays x (64+128) samples, {mode} step, numpy oracle, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from nerf_siren_amd import Embedding, NeRF, render_rays, synth
+    from nerf_siren_amd import ops
+    from nerf_siren_amd.parallel import FlatGradAllReduce
+
+    B = args.batch
+    models = []
+    for seed in (1, 2):
+        m = NeRF()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
+        models.append(m.to(dev))
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    # a pool of batches resident in HBM before the timed region (each rank its own shard of rays)
+    n_pool = 8
+    rays_pool = [torch.from_numpy(synth.blender_rays(B, seed=1000 * rank + i)).to(dev) for i in range(n_pool)]
+    tgt_pool = [torch.from_numpy(synth.hash_uniform((B, 3), 77 + 1000 * rank + i)).to(dev) for i in range(n_pool)]
+
+    train = args.mode == "train"
+    if train:
+        params = [p for m in models for p in m.parameters()]
+        opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8)       # utils/__init__.py:20, opt.py
+        reducer = FlatGradAllReduce(models, world)
+
+    # ---- per-kernel timing of the dominant kernel (fine MLP forward) -------------------------
+    ev = []
+    orig_fwd = ops.nerf_forward_rays
+
+    def timed_fwd(packed, rays, z, sigma_only=False, save=False):
+        if z.shape[1] != 128:
+            return orig_fwd(packed, rays, z, sigma_only, save)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = orig_fwd(packed, rays, z, sigma_only, save)
+        b.record()
+        ev.append((a, b))
+        return out
+
+    import nerf_siren_amd.rendering as R
+    R.ops.nerf_forward_rays = timed_fwd
+
+    def step(i):
+        rays = rays_pool[i % n_pool]
+        if train:
+            res = render_rays(models, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, True, False)
+            t = tgt_pool[i % n_pool]
+            loss = ((res["rgb_coarse"] - t) ** 2).mean() + ((res["rgb_fine"] - t) ** 2).mean()   # losses.py:15-20
+            opt.zero_grad(set_to_none=False)
+            loss.backward()
+            reducer.all_reduce()
+            opt.step()
+        else:
+            with torch.no_grad():
+                render_rays(models, emb, rays, 64, False, 0, 0, 64, 1024 * 32, True, True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ev.clear()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    flops_per_launch = B * 128 * FLOP_FULL
+    achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        total_samples = world * B * 192 * args.steps
+        out = {
+            "metric": "ray-samples/sec, Blender-lego 400x400 synthetic rays, 64c+64f"
+                      + (" (training step)" if train else " (inference, test_time)"),
+            "value": total_samples / dt, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: Blender-lego 400x400 rays, N_samples=64 N_importance=64, "
+                                   f"batch_size={B} rays/GPU, NeRF 8x256 coarse+fine, mode={args.mode}",
+                       "rays_per_gpu": B, "samples_per_ray": 192, "mode": args.mode,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "rays_per_s": world * B * args.steps / dt,
+            "roofline": {"bound": "mfma", "kernel": "nerf_forward_kernel (fine MLP, 128 samples/ray)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA, "traffic": None,
+                         "flops_per_launch": flops_per_launch, "avg_launch_ms": kern_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n_cpu = args.cpu_rays or (96 if train else 256)
+            out["cpu_baseline"] = cpu_baseline(args.mode, n_cpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,7 +69,7 @@ __device__ __forceinline__ double wave_incl_sum_d(double v, int lane) {
 __device__ __forceinline__ float ray_norm(float dx, float dy, float dz) {
     float s = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
     s = __fadd_rn(s, __fmul_rn(dz, dz));
-    return __fsqrt_rn(s);
+    return (float)sqrt((double)s);   // correctly rounded (fp64 sqrt of an fp32 value rounds innocuously)
 }
 
 }  // namespace nerfmi

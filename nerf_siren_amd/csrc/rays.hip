@@ -112,7 +112,9 @@ __device__ __forceinline__ void composite_forward_ray(RaySamples<SPL> &R, const 
         delta = __fmul_rn(delta, dn);                                        // :168
         float sg = sigma;
         if (noise_row) sg = __fadd_rn(sigma, __fmul_rn(noise_row[sc], noise_std));   // :170,173
-        const float e = expf(-__fmul_rn(delta, fmaxf(sg, 0.f)));
+        // exp evaluated in fp64 and rounded once: the correctly rounded fp32 value, which is what
+        // the oracle specifies (torch's SLEEF expf is within 1 ulp of it)
+        const float e = (float)exp((double)(-__fmul_rn(delta, fmaxf(sg, 0.f))));
         const float alpha = ok ? __fsub_rn(1.0f, e) : 0.f;                   // :173
         const float a = ok ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;  // :175
         R.alpha[j] = alpha; R.a[j] = a; R.z[j] = z0; R.e[j] = e; R.delta[j] = delta; R.sg[j] = sg;

@@ -130,7 +130,8 @@ def test_composite(golden, ops, dev, tag):
     field = np.concatenate([rgb, sig[..., None]], -1)
     w, c, d, o = [N(t) for t in ops.composite(T(field, dev), T(z, dev), T(rays, dev), T(noise, dev), nstd, wb)]
     r = O.composite(sig, rgb, z, rays[:, 3:6], noise, nstd, wb)
-    np.testing.assert_allclose(w, r["weights"], atol=2.4e-7, rtol=1e-6)     # exp: <=1 ulp libm difference
+    assert (w == r["weights"]).mean() > 0.999                               # same specified arithmetic
+    np.testing.assert_allclose(w, r["weights"], atol=2.4e-7, rtol=1e-6)
     np.testing.assert_allclose(o, r["opacity"], atol=4e-7, rtol=0)
     np.testing.assert_allclose(c, r["rgb"], atol=4e-7, rtol=0)
     np.testing.assert_allclose(d, r["depth"], atol=3e-6, rtol=0)
@@ -154,6 +155,7 @@ def test_composite_ragged_sizes(ops, dev, P):
     field = np.concatenate([rgb, sig[..., None]], -1)
     w, c, d, o = [N(t) for t in ops.composite(T(field, dev), T(z, dev), T(rays, dev), None, 0.0, False)]
     r = O.composite(sig, rgb, z, rays[:, 3:6], None, 0.0, False)
+    assert (w == r["weights"]).mean() > 0.999                 # same specified arithmetic (fp64 exp + scan)
     np.testing.assert_allclose(w, r["weights"], atol=2.4e-7, rtol=1e-6)
     np.testing.assert_allclose(c, r["rgb"], atol=5e-7, rtol=0)
     np.testing.assert_allclose(d, r["depth"], atol=5e-7, rtol=0)
