@@ -9,13 +9,9 @@
 // pre-packed, fully coalesced 1 KiB fragments through a small register ring; no
 // LDS, no barrier: the four waves of a workgroup are independent and each SIMD
 // runs one wave that issues MFMAs back to back.
-#include "common.h"
-#include "mlp_layout.h"
+#include "mlp_core.h"
 
 namespace nerfmi {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __constant__ LayerDesc d_layers[NL_FWD] = {
     LAYERS[0], LAYERS[1], LAYERS[2], LAYERS[3], LAYERS[4], LAYERS[5], LAYERS[6], LAYERS[7], LAYERS[8], LAYERS[9]};
@@ -74,85 +70,6 @@ __global__ void pack_kernel(ParamPtrs P, float *__restrict__ packed) {
         }
         packed[idx] = v;
     }
-}
-
-// ---------------------------------------------------------------------------
-// one dense layer on the matrix cores
-// ---------------------------------------------------------------------------
-constexpr int PF = 6;  // weight-fragment groups in flight per wave (1 KiB each)
-
-__device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
-
-// acc[jb] = bias + W[jb-block rows] . [in0 ; in1]     (JB x (KB0+KB1) blocks)
-// wp: this layer's packed image + lane*4;  bias: natural order + 4*half
-template <int KB0, int KB1, int JB>
-__device__ __forceinline__ void layer_mfma(const float *__restrict__ wp, const float *__restrict__ bias,
-                                           const f32x16 *in0, const f32x16 *in1, f32x16 *acc) {
-    constexpr int KBT = KB0 + KB1;
-    constexpr int G = JB * KBT * 4;
-    f32x4 ring[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) ring[i] = ldg4(wp + i * 256);
-#pragma unroll
-    for (int jb = 0; jb < JB; ++jb) {
-        f32x16 c;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = ldg4(bias + 32 * jb + 8 * q);
-            c[4 * q + 0] = b[0]; c[4 * q + 1] = b[1]; c[4 * q + 2] = b[2]; c[4 * q + 3] = b[3];
-        }
-#pragma unroll
-        for (int kb = 0; kb < KBT; ++kb) {
-            const f32x16 B = (kb < KB0) ? in0[kb] : in1[kb - KB0];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                constexpr int dummy = 0; (void)dummy;
-                const int g = (jb * KBT + kb) * 4 + q;
-                const f32x4 a = ring[g % PF];
-                if (g + PF < G) ring[g % PF] = ldg4(wp + (g + PF) * 256);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], B[4 * q + 0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], B[4 * q + 1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], B[4 * q + 2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], B[4 * q + 3], c, 0, 0, 0);
-            }
-        }
-        acc[jb] = c;
-    }
-}
-
-template <int NB>
-__device__ __forceinline__ void relu_copy(f32x16 *dst, const f32x16 *src) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[b][r] = fmaxf(src[b][r], 0.f);
-}
-
-// store NB blocks as [row][point]: row = row0 + 32*b + 8*(r>>2) + 4*half + (r&3)
-template <int NB>
-__device__ __forceinline__ void save_blocks(float *__restrict__ saved, int64_t ld, int row0, int half, int64_t p,
-                                            bool ok, const f32x16 *v) {
-    if (!ok) return;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            saved[(int64_t)(row0 + 32 * b + 8 * (r >> 2) + 4 * half + (r & 3)) * ld + p] = v[b][r];
-}
-
-// dot of the lane's share of a [NB x 16] block set with a natural-order vector
-template <int NB>
-__device__ __forceinline__ float dot_blocks(const f32x16 *v, const float *__restrict__ w_half) {
-    float s = 0.f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 w = ldg4(w_half + 32 * b + 8 * q);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) s = __builtin_fmaf(w[t], v[b][4 * q + t], s);
-        }
-    return s + __shfl_xor(s, 32, WAVE);
 }
 
 // Embedding(3,10) of this lane's point, as the two B-operand blocks of layer 1
@@ -214,6 +131,8 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
     const int64_t praw = p0 + (lane & 31);
     const bool ok = praw < n_points;
     const int64_t p = ok ? praw : n_points - 1;
+    RowImage S;
+    S.base = saved; S.ld = ld; S.lane_off = (unsigned)(4 * half * ld + praw); S.ok = ok;
 
     f32x16 e[2], de[1];
     if (EMBEDDED) {
@@ -245,25 +164,36 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         if (!SIGMA_ONLY) embed_dir_block(rr[3], rr[4], rr[5], half, de[0]);
     }
     if (SAVE) {
-        save_blocks<2>(saved, ld, S_EMB, half, p, ok, e);
-        if (!SIGMA_ONLY) save_blocks<1>(saved, ld, S_DEMB, half, p, ok, de);
+        store_block(S, S_EMB, e[0]);
+        store_block(S, S_EMB + 32, e[1]);
+        store_block(S, S_DEMB, de[0]);
     }
 
     const float *wl = packed + lane * 4;
     const float *bias = packed + OFF_BIAS + 4 * half;
     f32x16 h[8], acc[8];
 
-    layer_mfma<2, 0, 8>(wl + OFF_L1, bias, e, nullptr, acc);
-    relu_copy<8>(h, acc);
-    if (SAVE) save_blocks<8>(saved, ld, S_H, half, p, ok, h);
+    // ReLU epilogue; in training each finished block goes straight to the [row][point] image
+    auto relu_epi = [&](int row0) {
+        return [&S, row0](int jb, f32x16 c) {
+            c = relu16(c);
+            if (SAVE) store_block(S, row0 + 32 * jb, c);
+            return c;
+        };
+    };
+    auto copy8 = [&]() {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) h[b] = acc[b];
+    };
+
+    layer_mfma<2, 0, 8>(wl + OFF_L1, bias, e, nullptr, acc, relu_epi(S_H));
+    copy8();
     for (int l = 1; l <= 3; ++l) {
-        layer_mfma<8, 0, 8>(wl + OFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc);
-        relu_copy<8>(h, acc);
-        if (SAVE) save_blocks<8>(saved, ld, S_H + 256 * l, half, p, ok, h);
+        layer_mfma<8, 0, 8>(wl + OFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, relu_epi(S_H + 256 * l));
+        copy8();
     }
-    layer_mfma<2, 8, 8>(wl + OFF_L5, bias + 256 * 4, e, h, acc);
-    relu_copy<8>(h, acc);
-    if (SAVE) save_blocks<8>(saved, ld, S_H + 256 * 4, half, p, ok, h);
+    layer_mfma<2, 8, 8>(wl + OFF_L5, bias + 256 * 4, e, h, acc, relu_epi(S_H + 256 * 4));
+    copy8();
 
     float sigma = 0.f;
     for (int l = 5; l <= 8; ++l) {   // xyz_encoding_6..8, then xyz_encoding_final (no ReLU)
@@ -271,24 +201,22 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
             sigma = dot_blocks<8>(h, packed + OFF_W_SIGMA + 4 * half) + packed[OFF_B_SIGMA];
             if (SIGMA_ONLY) break;
         }
-        layer_mfma<8, 0, 8>(wl + OFF_L6 + (l - 5) * SZ_HID, bias + 256 * l, h, nullptr, acc);
-        if (l < 8) {
-            relu_copy<8>(h, acc);
-            if (SAVE) save_blocks<8>(saved, ld, S_H + 256 * l, half, p, ok, h);
-        } else {
-#pragma unroll
-            for (int b = 0; b < 8; ++b) h[b] = acc[b];
-            if (SAVE) save_blocks<8>(saved, ld, S_FINAL, half, p, ok, h);
-        }
+        const bool last = (l == 8);
+        const int row0 = last ? S_FINAL : S_H + 256 * l;
+        layer_mfma<8, 0, 8>(wl + OFF_L6 + (l - 5) * SZ_HID, bias + 256 * l, h, nullptr, acc,
+                            [&S, row0, last](int jb, f32x16 c) {
+                                if (!last) c = relu16(c);
+                                if (SAVE) store_block(S, row0 + 32 * jb, c);
+                                return c;
+                            });
+        copy8();
     }
     if (SIGMA_ONLY) {
         if (ok && half == 0) out[p] = sigma;
         return;
     }
     f32x16 dh[4];
-    layer_mfma<8, 1, 4>(wl + OFF_DIR, packed + OFF_BIAS_DIR + 4 * half, h, de, acc);
-    relu_copy<4>(dh, acc);
-    if (SAVE) save_blocks<4>(saved, ld, S_DIRH, half, p, ok, dh);
+    layer_mfma<8, 1, 4>(wl + OFF_DIR, packed + OFF_BIAS_DIR + 4 * half, h, de, dh, relu_epi(S_DIRH));
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -299,11 +227,11 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         float4 o;
         o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2]; o.w = sigma;
         reinterpret_cast<float4 *>(out)[p] = o;
-        if (SAVE) {
-            saved[(int64_t)(S_RGB + 0) * ld + p] = rgb[0];
-            saved[(int64_t)(S_RGB + 1) * ld + p] = rgb[1];
-            saved[(int64_t)(S_RGB + 2) * ld + p] = rgb[2];
-        }
+    }
+    if (SAVE && half == 0) {
+        S.row(S_RGB + 0)[praw] = ok ? rgb[0] : 0.f;
+        S.row(S_RGB + 1)[praw] = ok ? rgb[1] : 0.f;
+        S.row(S_RGB + 2)[praw] = ok ? rgb[2] : 0.f;
     }
 }
 

@@ -1,17 +1,385 @@
-// NeRF MLP backward (placeholder until the dX-chain / dW kernels land).
-#include "common.h"
-#include "mlp_layout.h"
+// NeRF MLP backward for gfx950 (MI355X): autograd of models/nerf.py:83-124
+// w.r.t. the 24 parameters (SURVEY section 8a backward contract).
+//
+//  1. nerf_backward_chain_kernel -- the dX chain.  Same register-resident scheme
+//     as the forward (mlp_core.h): a wave owns 32 points, dZ_l^T lives in the
+//     accumulator layout and is the B operand of  dH_{l-1}^T = W_l^T . dZ_l^T
+//     (A = the transposed packed image).  ReLU masks come from the saved
+//     post-activation images; every dZ_l is written to the workspace as a
+//     [unit][point] image.
+//  2. nerf_dw_kernel -- dW_l = dZ_l^T . X_l, a (units x units x points) GEMM whose
+//     contraction runs over POINTS.  Both operands are [unit][point] images, so a
+//     32-point tile of A and B rows is staged through LDS with full 128-B row
+//     segments and consumed by v_mfma_f32_32x32x2_f32; the point range is split
+//     into chunks (split-K) and every workgroup writes its partial slab.
+//  3. nerf_dw_reduce_kernel -- deterministic slab reduction into the (out,in)
+//     gradient tensors (no float atomics: results are bit-reproducible).
+#include "mlp_core.h"
+
+namespace nerfmi {
+
+// workspace row map ([row][point] images written by the chain kernel)
+constexpr int W_DZ = 0;                  // 8 x 256: dZ of xyz_encoding_1..8 (masked by ReLU)
+constexpr int W_DFINAL = 8 * 256;        // 256: d xyz_encoding_final output
+constexpr int W_DDIR = W_DFINAL + 256;   // 128: dZ of dir_encoding
+constexpr int W_DRGB = W_DDIR + 128;     // 3 (+1 pad): d rgb pre-sigmoid
+constexpr int W_DSIG = W_DRGB + 4;       // 1 (+3 pad): d sigma
+constexpr int W_ROWS = W_DSIG + 4;
+
+// ---------------------------------------------------------------------------
+// 1. dX chain
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__restrict__ saved,
+                           const float *__restrict__ grad_out, int64_t n_points, int64_t ld,
+                           float *__restrict__ work) {
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t p0 = wave * 32;
+    if (p0 >= n_points) return;
+    const int64_t praw = p0 + (lane & 31);
+    const bool ok = praw < n_points;
+    RowImage S, Wk;
+    S.base = const_cast<float *>(saved); S.ld = ld; S.lane_off = (unsigned)(4 * half * ld + praw); S.ok = ok;
+    Wk.base = work; Wk.ld = ld; Wk.lane_off = S.lane_off; Wk.ok = ok;
+
+    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) go = reinterpret_cast<const float4 *>(grad_out)[praw];
+    // rgb = sigmoid(pre): d pre = d rgb * rgb * (1 - rgb)      (nerf.py:78-80)
+    float dpre[3];
+    {
+        const float g3[3] = {go.x, go.y, go.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float rgb = S.row(S_RGB + c)[praw];
+            dpre[c] = g3[c] * rgb * (1.0f - rgb);
+            if (half == 0) Wk.row(W_DRGB + c)[praw] = dpre[c];
+        }
+        if (half == 0) Wk.row(W_DSIG)[praw] = go.w;
+    }
+    const float dsig = go.w;
+
+    f32x16 dz[8], acc[8];
+    // d dir_h = W_rgb^T d pre, masked by the saved ReLU output     (nerf.py:119-120)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const f32x16 act = load_block(S, S_DIRH + 32 * b);
+        f32x16 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 w[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w[c] = ldg4(packed + OFF_W_RGB + 128 * c + 32 * b + 8 * q + 4 * half);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float s = __builtin_fmaf(w[2][t], dpre[2], __builtin_fmaf(w[1][t], dpre[1], w[0][t] * dpre[0]));
+                v[4 * q + t] = act[4 * q + t] > 0.f ? s : 0.f;
+            }
+        }
+        dz[b] = v;
+        store_block(Wk, W_DDIR + 32 * b, v);
+    }
+    const float *wl = packed + lane * 4;
+    // d final = W_dir[:, :256]^T dZ_dir                          (nerf.py:116-118; no activation on final)
+    layer_mfma<4, 0, 8>(wl + OFF_TDIR, nullptr, dz, nullptr, acc, [&Wk](int jb, f32x16 c) {
+        store_block(Wk, W_DFINAL + 32 * jb, c);
+        return c;
+    });
+#pragma unroll
+    for (int b = 0; b < 8; ++b) dz[b] = acc[b];
+    // d h8 = W_final^T d final + w_sigma d sigma, masked by h8 > 0 (nerf.py:112-116)
+    layer_mfma<8, 0, 8>(wl + OFF_TFINAL, nullptr, dz, nullptr, acc, [&](int jb, f32x16 c) {
+        const f32x16 act = load_block(S, S_H + 7 * 256 + 32 * jb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w = ldg4(packed + OFF_W_SIGMA + 32 * jb + 8 * q + 4 * half);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float v = __builtin_fmaf(w[t], dsig, c[4 * q + t]);
+                c[4 * q + t] = act[4 * q + t] > 0.f ? v : 0.f;
+            }
+        }
+        store_block(Wk, W_DZ + 7 * 256 + 32 * jb, c);
+        return c;
+    });
+#pragma unroll
+    for (int b = 0; b < 8; ++b) dz[b] = acc[b];
+    // xyz_encoding_8 .. xyz_encoding_2: d h_{l-1} = W_l[:, hidden]^T dZ_l, masked by h_{l-1} > 0
+    for (int li = 7; li >= 1; --li) {
+        const int srow = S_H + (li - 1) * 256, wrow = W_DZ + (li - 1) * 256;
+        layer_mfma<8, 0, 8>(wl + OFF_T2 + (li - 1) * SZ_HID, nullptr, dz, nullptr, acc, [&](int jb, f32x16 c) {
+            const f32x16 act = load_block(S, srow + 32 * jb);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = act[r] > 0.f ? c[r] : 0.f;
+            store_block(Wk, wrow + 32 * jb, c);
+            return c;
+        });
+#pragma unroll
+        for (int b = 0; b < 8; ++b) dz[b] = acc[b];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 2. dW = dZ^T . X over points
+// ---------------------------------------------------------------------------
+struct DwTask {
+    int kind;       // template instance 0..5
+    int a_row0;     // first dZ row in the workspace
+    int a_valid;    // real rows (others read as 0)
+    int b_row0;     // first X row in the saved image
+    int b_valid;
+    int param;      // weight tensor index
+    int out_col0;   // first column of the weight this task covers
+    int in_f;       // row stride of the weight tensor
+    int bias_param; // bias tensor index or -1
+    int chunks;     // split of the point range
+    int wg0;        // first workgroup of this task
+    int part_off;   // float offset of this task's slabs in the partial buffer
+    int JB, KB;     // block counts (rows/cols of the slab = 32*JB x 32*KB)
+};
+constexpr int MAX_TASKS = 16;
+struct DwPlan {
+    DwTask t[MAX_TASKS];
+    int n_tasks;
+    int n_wg;
+};
+
+constexpr int LROW = 36;   // LDS row pitch in floats: 32 points + 4 pad (conflict-free ds_read_b128)
+
+template <int JW, int KW, int WJ, int WK>
+__device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float *__restrict__ work,
+                                        const float *__restrict__ saved, int64_t ld, float *__restrict__ partial,
+                                        float *lds) {
+    constexpr int JB = JW * WJ, KB = KW * WK;
+    constexpr int ROWS = (JB + KB) * 32;
+    constexpr int NLD = ROWS / 32;            // float4 staging registers per thread
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
+    const int wj = wid / WK, wk = wid % WK;
+    const int64_t tiles = ld / 32;
+    const int64_t t_lo = tiles * chunk / T.chunks, t_hi = tiles * (chunk + 1) / T.chunks;
+
+    // global sources of this thread's staging slots
+    const float *src[NLD];
+    bool valid[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int u = i * 256 + tid, row = u >> 3, c4 = u & 7;
+        if (row < JB * 32) {
+            valid[i] = row < T.a_valid;
+            src[i] = work + (int64_t)(T.a_row0 + (valid[i] ? row : 0)) * ld + 4 * c4;
+        } else {
+            const int rb = row - JB * 32;
+            valid[i] = rb < T.b_valid;
+            src[i] = saved + (int64_t)(T.b_row0 + (valid[i] ? rb : 0)) * ld + 4 * c4;
+        }
+    }
+    f32x16 acc[JW][KW];
+#pragma unroll
+    for (int a = 0; a < JW; ++a)
+#pragma unroll
+        for (int b = 0; b < KW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[JW];
+#pragma unroll
+    for (int a = 0; a < JW; ++a) bsum[a] = 0.f;
+
+    f32x4 stage[NLD];
+    auto load_tile = [&](int64_t t) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            stage[i] = ldg4(src[i] + t * 32);
+            if (!valid[i]) stage[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (t_lo < t_hi) load_tile(t_lo);
+    for (int64_t t = t_lo; t < t_hi; ++t) {
+        __syncthreads();                       // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int u = i * 256 + tid, row = u >> 3, c4 = u & 7;
+            *reinterpret_cast<f32x4 *>(lds + row * LROW + 4 * c4) = stage[i];
+        }
+        __syncthreads();
+        if (t + 1 < t_hi) load_tile(t + 1);    // in flight under the MFMAs below
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a[JW], b[KW];
+#pragma unroll
+            for (int x = 0; x < JW; ++x)
+                a[x] = *reinterpret_cast<const f32x4 *>(lds + (32 * (wj * JW + x) + (lane & 31)) * LROW + 8 * q + 4 * half);
+#pragma unroll
+            for (int x = 0; x < KW; ++x)
+                b[x] = *reinterpret_cast<const f32x4 *>(lds + (32 * (JB + wk * KW + x) + (lane & 31)) * LROW + 8 * q + 4 * half);
+#pragma unroll
+            for (int x = 0; x < JW; ++x) bsum[x] += (a[x][0] + a[x][1]) + (a[x][2] + a[x][3]);
+#pragma unroll
+            for (int x = 0; x < JW; ++x)
+#pragma unroll
+                for (int y = 0; y < KW; ++y)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x][s], b[y][s], acc[x][y], 0, 0, 0);
+        }
+    }
+    // partial slab [chunk][32*JB][32*KB] then bias slab [chunk][32*JB]
+    float *slab = partial + T.part_off + (int64_t)chunk * (JB * 32 * (KB * 32 + 1));
+#pragma unroll
+    for (int x = 0; x < JW; ++x)
+#pragma unroll
+        for (int y = 0; y < KW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * (wj * JW + x) + 8 * (r >> 2) + 4 * half + (r & 3);
+                const int k = 32 * (wk * KW + y) + (lane & 31);
+                slab[j * (KB * 32) + k] = acc[x][y][r];
+            }
+    if (wk == 0) {
+#pragma unroll
+        for (int x = 0; x < JW; ++x) {
+            const float s = bsum[x] + __shfl_xor(bsum[x], 32, WAVE);
+            if (half == 0) slab[JB * 32 * KB * 32 + 32 * (wj * JW + x) + lane] = s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+nerf_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__restrict__ saved, int64_t ld,
+               float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int ti = 0;
+    for (int i = 1; i < plan.n_tasks; ++i)
+        if ((int)blockIdx.x >= plan.t[i].wg0) ti = i;
+    const DwTask T = plan.t[ti];
+    const int chunk = blockIdx.x - T.wg0;
+    switch (T.kind) {
+        case 0: dw_task<2, 8, 4, 1>(T, chunk, work, saved, ld, partial, lds); break;
+        case 1: dw_task<2, 2, 4, 1>(T, chunk, work, saved, ld, partial, lds); break;
+        case 2: dw_task<1, 8, 4, 1>(T, chunk, work, saved, ld, partial, lds); break;
+        case 3: dw_task<1, 1, 4, 1>(T, chunk, work, saved, ld, partial, lds); break;
+        case 4: dw_task<1, 1, 1, 4>(T, chunk, work, saved, ld, partial, lds); break;
+        default: dw_task<1, 2, 1, 4>(T, chunk, work, saved, ld, partial, lds); break;
+    }
+}
+
+struct GradPtrs {
+    float *p[N_PARAMS];
+};
+
+// 3. slab reduction: blockIdx.y = task
+__global__ void nerf_dw_reduce_kernel(DwPlan plan, const float *__restrict__ partial, GradPtrs G) {
+    const DwTask T = plan.t[blockIdx.y];
+    const int rows = T.JB * 32, cols = T.KB * 32;
+    const int slab = rows * (cols + 1);
+    const int out_f_valid = T.a_valid, in_valid = T.b_valid;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < slab; idx += gridDim.x * blockDim.x) {
+        const float *src = partial + T.part_off + idx;
+        float s = 0.f;
+        for (int c = 0; c < T.chunks; ++c) s += src[(int64_t)c * slab];
+        if (idx < rows * cols) {
+            const int j = idx / cols, k = idx % cols;
+            if (j < out_f_valid && k < in_valid) G.p[T.param][j * T.in_f + T.out_col0 + k] = s;
+        } else if (T.bias_param >= 0) {
+            const int j = idx - rows * cols;
+            if (j < out_f_valid) G.p[T.bias_param][j] = s;
+        }
+    }
+}
+
+static const int KIND_JB[6] = {8, 8, 4, 4, 1, 1};
+static const int KIND_KB[6] = {8, 2, 8, 1, 4, 8};
+
+static DwPlan make_plan(int64_t ld) {
+    DwPlan P;
+    int n = 0;
+    auto add = [&](int kind, int a_row0, int a_valid, int b_row0, int b_valid, int param, int col0, int in_f, int bias) {
+        DwTask &t = P.t[n++];
+        t.kind = kind; t.a_row0 = a_row0; t.a_valid = a_valid; t.b_row0 = b_row0; t.b_valid = b_valid;
+        t.param = param; t.out_col0 = col0; t.in_f = in_f; t.bias_param = bias;
+        t.JB = KIND_JB[kind]; t.KB = KIND_KB[kind];
+    };
+    add(1, W_DZ, 256, S_EMB, 63, 0, 0, 63, 1);                                       // xyz_encoding_1
+    for (int li = 1; li <= 3; ++li) add(0, W_DZ + 256 * li, 256, S_H + 256 * (li - 1), 256, 2 * li, 0, 256, 2 * li + 1);
+    add(1, W_DZ + 256 * 4, 256, S_EMB, 63, 8, 0, 319, -1);                           // xyz_encoding_5, skip part
+    add(0, W_DZ + 256 * 4, 256, S_H + 256 * 3, 256, 8, 63, 319, 9);                  // xyz_encoding_5, hidden part
+    for (int li = 5; li <= 7; ++li) add(0, W_DZ + 256 * li, 256, S_H + 256 * (li - 1), 256, 2 * li, 0, 256, 2 * li + 1);
+    add(0, W_DFINAL, 256, S_H + 256 * 7, 256, 16, 0, 256, 17);                       // xyz_encoding_final
+    add(2, W_DDIR, 128, S_FINAL, 256, 18, 0, 283, 19);                               // dir_encoding, final part
+    add(3, W_DDIR, 128, S_DEMB, 27, 18, 256, 283, -1);                               // dir_encoding, dir-emb part
+    add(4, W_DRGB, 3, S_DIRH, 128, PARAM_RGB_W, 0, 128, PARAM_RGB_B);                // rgb
+    add(5, W_DSIG, 1, S_H + 256 * 7, 256, PARAM_SIGMA_W, 0, 256, PARAM_SIGMA_B);     // sigma
+    P.n_tasks = n;
+    // chunks proportional to MFMA work so that every workgroup costs the same and the grid is <= 256 (one per CU)
+    static const int base[6] = {24, 6, 12, 2, 2, 3};
+    const int64_t tiles = ld / 32;
+    int wg = 0, off = 0;
+    for (int i = 0; i < n; ++i) {
+        DwTask &t = P.t[i];
+        int c = base[t.kind];
+        if (c > tiles) c = (int)(tiles < 1 ? 1 : tiles);
+        t.chunks = c; t.wg0 = wg; t.part_off = off;
+        wg += c;
+        off += c * (t.JB * 32 * (t.KB * 32 + 1));
+    }
+    P.n_wg = wg;
+    return P;
+}
+
+static size_t plan_partial_floats(const DwPlan &P) {
+    const DwTask &t = P.t[P.n_tasks - 1];
+    return (size_t)t.part_off + (size_t)t.chunks * (t.JB * 32 * (t.KB * 32 + 1));
+}
+
+static inline int64_t pad_points(int64_t n) { return (n + 31) / 32 * 32; }
+
+}  // namespace nerfmi
 
 using namespace nerfmi;
 
 extern "C" {
 
-size_t nerfmi_nerf_backward_workspace_floats(int64_t n_points) { (void)n_points; return 4; }
+size_t nerfmi_nerf_backward_workspace_floats(int64_t n_points) {
+    const int64_t ld = pad_points(n_points < 1 ? 1 : n_points);
+    const DwPlan P = make_plan(ld);
+    return (size_t)W_ROWS * (size_t)ld + plan_partial_floats(P);
+}
 
-int nerfmi_nerf_backward_rays(const float *, const float *, const float *, int, int, const float *, const float *,
-                              float *const *, float *, nerfmi_stream_t) {
-    set_error("nerf_backward_rays: not implemented yet");
-    return NERFMI_E_UNSUPPORTED;
+int nerfmi_nerf_backward_rays(const float *packed, const float *rays, const float *z, int n_rays, int n_per_ray,
+                              const float *saved, const float *grad_out, float *const *grad_params,
+                              float *workspace, nerfmi_stream_t stream) {
+    (void)rays; (void)z;   // inputs carry no gradient (rendering.py:54, :244); kept for ABI symmetry
+    NERFMI_REQUIRE(n_rays >= 1 && n_per_ray >= 1, "nerf_backward_rays: bad sizes");
+    NERFMI_REQUIRE(packed && saved && grad_out && grad_params && workspace, "nerf_backward_rays: null pointer");
+    const int64_t n_points = (int64_t)n_rays * n_per_ray;
+    const int64_t ld = pad_points(n_points);
+    NERFMI_REQUIRE(5 * ld * 4 < ((int64_t)1 << 32), "nerf_backward_rays: n_points too large for 32-bit lane offsets");
+    GradPtrs G;
+    for (int i = 0; i < N_PARAMS; ++i) {
+        NERFMI_REQUIRE(grad_params[i], "nerf_backward_rays: grad_params[%d] is null", i);
+        G.p[i] = grad_params[i];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float *work = workspace;
+    float *partial = workspace + (size_t)W_ROWS * ld;
+    const int64_t waves = (n_points + 31) / 32;
+    hipLaunchKernelGGL(nerf_backward_chain_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
+                       grad_out, n_points, ld, work);
+    const DwPlan P = make_plan(ld);
+    const size_t lds = sizeof(float) * 512 * LROW;      // 73 728 B > the 64 KiB default dynamic-LDS limit
+    static thread_local bool lds_attr_set = false;
+    if (!lds_attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("nerf_backward_rays: cannot raise the dynamic LDS limit to %zu bytes", lds);
+            return NERFMI_E_LAUNCH;
+        }
+        lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(nerf_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
+    hipLaunchKernelGGL(nerf_dw_reduce_kernel, dim3(64, P.n_tasks), dim3(256), 0, st, P, partial, G);
+    return check_launch("nerf_backward_rays");
 }
 
 }  // extern "C"

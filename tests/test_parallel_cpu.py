@@ -1,0 +1,78 @@
+"""world_size-2 gloo test of the data-parallel glue (runs on CPU): sharded rays +
+flat-gradient all-reduce(mean) == single-process gradient of the mean loss."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nerf_siren_amd.parallel import FlatGradAllReduce, shard_rays
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _models():
+    torch.manual_seed(0)
+    return [torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3)),
+            torch.nn.Linear(8, 3)]
+
+
+def _loss(models, rays):
+    return sum(((m(rays)) ** 2).mean() for m in models)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1)
+    rays = torch.randn(64, 8)
+    lo, hi = shard_rays(64, rank, world)
+    models = _models()
+    red = FlatGradAllReduce(models, world)
+    red.zero_()
+    _loss(models, rays[lo:hi]).backward()
+    flat = red.all_reduce().clone()
+    # every p.grad is a view into the flat buffer
+    assert all(p.grad.data_ptr() >= red.flat.data_ptr() for p in red.params)
+    q.put((rank, flat))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_flat_grad_allreduce_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    torch.manual_seed(1)
+    rays = torch.randn(64, 8)
+    models = _models()
+    _loss(models, rays).backward()              # equal shards -> mean of shard losses == full mean
+    ref = torch.cat([p.grad.reshape(-1) for m in models for p in m.parameters()])
+    for r in range(world):
+        assert torch.allclose(got[r], ref, atol=1e-6), r
+    assert torch.equal(got[0], got[1])
+
+
+def test_shard_rays_partition():
+    for n, w in ((1024, 8), (10, 3), (5, 8), (0, 2)):
+        spans = [shard_rays(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
