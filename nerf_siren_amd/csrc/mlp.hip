@@ -132,7 +132,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
     const bool ok = praw < n_points;
     const int64_t p = ok ? praw : n_points - 1;
     RowImage S;
-    S.base = saved; S.ld = ld; S.lane_off = (unsigned)(4 * half * ld + praw); S.ok = ok;
+    S.init(saved, wave, SAVED_ROWS, lane, ok);
 
     f32x16 e[2], de[1];
     if (EMBEDDED) {
@@ -173,11 +173,20 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
     const float *bias = packed + OFF_BIAS + 4 * half;
     f32x16 h[8], acc[8];
 
-    // ReLU epilogue; in training each finished block goes straight to the [row][point] image
+    // Stores share the in-order vmcnt queue with the weight loads: a wait for a weight fragment issued
+    // after a store also waits for that store's acknowledgement, so the training variant keeps more
+    // fragments in flight.
+    constexpr int PFK = SAVE ? 12 : PF_DEFAULT;
+    auto no_pre = [](int) { return 0; };
+    // ReLU epilogue; in training each finished block goes straight to the tile-major image
+    unsigned mk[4] = {0u, 0u, 0u, 0u};
     auto relu_epi = [&](int row0) {
-        return [&S, row0](int jb, f32x16 c) {
-            c = relu16(c);
-            if (SAVE) store_block(S, row0 + 32 * jb, c);
+        return [&S, &mk, row0](int jb, int q, f32x4 c, int) {
+            c = relu4(c);
+            if (SAVE) {
+                mask_or(mk, jb, q, c);
+                store_slice(S, row0 + 32 * jb, q, c);
+            }
             return c;
         };
     };
@@ -186,13 +195,16 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         for (int b = 0; b < 8; ++b) h[b] = acc[b];
     };
 
-    layer_mfma<2, 0, 8>(wl + OFF_L1, bias, e, nullptr, acc, relu_epi(S_H));
+    layer_mfma<2, 0, 8, PFK>(wl + OFF_L1, bias, e, nullptr, acc, no_pre, relu_epi(S_H));
+    if (SAVE) store_mask(S, 0, mk);
     copy8();
     for (int l = 1; l <= 3; ++l) {
-        layer_mfma<8, 0, 8>(wl + OFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, relu_epi(S_H + 256 * l));
+        layer_mfma<8, 0, 8, PFK>(wl + OFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, relu_epi(S_H + 256 * l));
+        if (SAVE) store_mask(S, l, mk);
         copy8();
     }
-    layer_mfma<2, 8, 8>(wl + OFF_L5, bias + 256 * 4, e, h, acc, relu_epi(S_H + 256 * 4));
+    layer_mfma<2, 8, 8, PFK>(wl + OFF_L5, bias + 256 * 4, e, h, acc, no_pre, relu_epi(S_H + 256 * 4));
+    if (SAVE) store_mask(S, 4, mk);
     copy8();
 
     float sigma = 0.f;
@@ -203,12 +215,16 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         }
         const bool last = (l == 8);
         const int row0 = last ? S_FINAL : S_H + 256 * l;
-        layer_mfma<8, 0, 8>(wl + OFF_L6 + (l - 5) * SZ_HID, bias + 256 * l, h, nullptr, acc,
-                            [&S, row0, last](int jb, f32x16 c) {
-                                if (!last) c = relu16(c);
-                                if (SAVE) store_block(S, row0 + 32 * jb, c);
+        layer_mfma<8, 0, 8, PFK>(wl + OFF_L6 + (l - 5) * SZ_HID, bias + 256 * l, h, nullptr, acc,
+                            no_pre, [&S, &mk, row0, last](int jb, int q, f32x4 c, int) {
+                                if (!last) c = relu4(c);
+                                if (SAVE) {
+                                    if (!last) mask_or(mk, jb, q, c);
+                                    store_slice(S, row0 + 32 * jb, q, c);
+                                }
                                 return c;
                             });
+        if (SAVE && !last) store_mask(S, l, mk);
         copy8();
     }
     if (SIGMA_ONLY) {
@@ -216,7 +232,8 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         return;
     }
     f32x16 dh[4];
-    layer_mfma<8, 1, 4>(wl + OFF_DIR, packed + OFF_BIAS_DIR + 4 * half, h, de, dh, relu_epi(S_DIRH));
+    layer_mfma<8, 1, 4, PFK>(wl + OFF_DIR, packed + OFF_BIAS_DIR + 4 * half, h, de, dh, no_pre, relu_epi(S_DIRH));
+    if (SAVE) store_mask(S, 8, mk);
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -229,9 +246,9 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         reinterpret_cast<float4 *>(out)[p] = o;
     }
     if (SAVE && half == 0) {
-        S.row(S_RGB + 0)[praw] = ok ? rgb[0] : 0.f;
-        S.row(S_RGB + 1)[praw] = ok ? rgb[1] : 0.f;
-        S.row(S_RGB + 2)[praw] = ok ? rgb[2] : 0.f;
+        *S.at(S_RGB + 0) = ok ? rgb[0] : 0.f;
+        *S.at(S_RGB + 1) = ok ? rgb[1] : 0.f;
+        *S.at(S_RGB + 2) = ok ? rgb[2] : 0.f;
     }
 }
 

@@ -6,11 +6,11 @@
 //     accumulator layout and is the B operand of  dH_{l-1}^T = W_l^T . dZ_l^T
 //     (A = the transposed packed image).  ReLU masks come from the saved
 //     post-activation images; every dZ_l is written to the workspace as a
-//     [unit][point] image.
+//     tile-major [tile][unit][32 points] image (mlp_core.h RowImage).
 //  2. nerf_dw_kernel -- dW_l = dZ_l^T . X_l, a (units x units x points) GEMM whose
-//     contraction runs over POINTS.  Both operands are [unit][point] images, so a
-//     32-point tile of A and B rows is staged through LDS with full 128-B row
-//     segments and consumed by v_mfma_f32_32x32x2_f32; the point range is split
+//     contraction runs over POINTS.  Both operands are tile-major images, so a
+//     32-point tile of A and B row ranges (contiguous, 128 B per row) is staged
+//     through LDS and consumed by v_mfma_f32_32x32x2_f32; the point range is split
 //     into chunks (split-K) and every workgroup writes its partial slab.
 //  3. nerf_dw_reduce_kernel -- deterministic slab reduction into the (out,in)
 //     gradient tensors (no float atomics: results are bit-reproducible).
@@ -18,7 +18,7 @@
 
 namespace nerfmi {
 
-// workspace row map ([row][point] images written by the chain kernel)
+// workspace row map (tile-major images written by the chain kernel)
 constexpr int W_DZ = 0;                  // 8 x 256: dZ of xyz_encoding_1..8 (masked by ReLU)
 constexpr int W_DFINAL = 8 * 256;        // 256: d xyz_encoding_final output
 constexpr int W_DDIR = W_DFINAL + 256;   // 128: dZ of dir_encoding
@@ -41,8 +41,8 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
     const int64_t praw = p0 + (lane & 31);
     const bool ok = praw < n_points;
     RowImage S, Wk;
-    S.base = const_cast<float *>(saved); S.ld = ld; S.lane_off = (unsigned)(4 * half * ld + praw); S.ok = ok;
-    Wk.base = work; Wk.ld = ld; Wk.lane_off = S.lane_off; Wk.ok = ok;
+    S.init(const_cast<float *>(saved), wave, SAVED_ROWS, lane, ok);
+    Wk.init(work, wave, W_ROWS, lane, ok);
 
     float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) go = reinterpret_cast<const float4 *>(grad_out)[praw];
@@ -52,19 +52,20 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
         const float g3[3] = {go.x, go.y, go.z};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float rgb = S.row(S_RGB + c)[praw];
+            const float rgb = *S.at(S_RGB + c);
             dpre[c] = g3[c] * rgb * (1.0f - rgb);
-            if (half == 0) Wk.row(W_DRGB + c)[praw] = dpre[c];
+            if (half == 0) *Wk.at(W_DRGB + c) = dpre[c];
         }
-        if (half == 0) Wk.row(W_DSIG)[praw] = go.w;
+        if (half == 0) *Wk.at(W_DSIG) = go.w;
     }
     const float dsig = go.w;
 
     f32x16 dz[8], acc[8];
-    // d dir_h = W_rgb^T d pre, masked by the saved ReLU output     (nerf.py:119-120)
+    unsigned mk[4];
+    // d dir_h = W_rgb^T d pre, masked by the saved ReLU sign bits  (nerf.py:119-120)
+    load_mask(S, 8, mk);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const f32x16 act = load_block(S, S_DIRH + 32 * b);
         f32x16 v;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -74,7 +75,7 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float s = __builtin_fmaf(w[2][t], dpre[2], __builtin_fmaf(w[1][t], dpre[1], w[0][t] * dpre[0]));
-                v[4 * q + t] = act[4 * q + t] > 0.f ? s : 0.f;
+                v[4 * q + t] = mask_bit(mk, b, q, t) ? s : 0.f;
             }
         }
         dz[b] = v;
@@ -82,39 +83,40 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
     }
     const float *wl = packed + lane * 4;
     // d final = W_dir[:, :256]^T dZ_dir                          (nerf.py:116-118; no activation on final)
-    layer_mfma<4, 0, 8>(wl + OFF_TDIR, nullptr, dz, nullptr, acc, [&Wk](int jb, f32x16 c) {
-        store_block(Wk, W_DFINAL + 32 * jb, c);
-        return c;
-    });
+    constexpr int PFK = 6;
+    layer_mfma<4, 0, 8, PFK>(wl + OFF_TDIR, nullptr, dz, nullptr, acc, [](int) { return 0; },
+                             [&Wk](int jb, int q, f32x4 c, int) {
+                                 store_slice(Wk, W_DFINAL + 32 * jb, q, c);
+                                 return c;
+                             });
 #pragma unroll
     for (int b = 0; b < 8; ++b) dz[b] = acc[b];
     // d h8 = W_final^T d final + w_sigma d sigma, masked by h8 > 0 (nerf.py:112-116)
-    layer_mfma<8, 0, 8>(wl + OFF_TFINAL, nullptr, dz, nullptr, acc, [&](int jb, f32x16 c) {
-        const f32x16 act = load_block(S, S_H + 7 * 256 + 32 * jb);
+    load_mask(S, 7, mk);
+    layer_mfma<8, 0, 8, PFK>(wl + OFF_TFINAL, nullptr, dz, nullptr, acc, [](int) { return 0; },
+                             [&](int jb, int q, f32x4 c, int) {
+                                 const f32x4 w = ldg4(packed + OFF_W_SIGMA + 32 * jb + 8 * q + 4 * half);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 w = ldg4(packed + OFF_W_SIGMA + 32 * jb + 8 * q + 4 * half);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float v = __builtin_fmaf(w[t], dsig, c[4 * q + t]);
-                c[4 * q + t] = act[4 * q + t] > 0.f ? v : 0.f;
-            }
-        }
-        store_block(Wk, W_DZ + 7 * 256 + 32 * jb, c);
-        return c;
-    });
+                                 for (int t = 0; t < 4; ++t) {
+                                     const float v = __builtin_fmaf(w[t], dsig, c[t]);
+                                     c[t] = mask_bit(mk, jb, q, t) ? v : 0.f;
+                                 }
+                                 store_slice(Wk, W_DZ + 7 * 256 + 32 * jb, q, c);
+                                 return c;
+                             });
 #pragma unroll
     for (int b = 0; b < 8; ++b) dz[b] = acc[b];
     // xyz_encoding_8 .. xyz_encoding_2: d h_{l-1} = W_l[:, hidden]^T dZ_l, masked by h_{l-1} > 0
     for (int li = 7; li >= 1; --li) {
-        const int srow = S_H + (li - 1) * 256, wrow = W_DZ + (li - 1) * 256;
-        layer_mfma<8, 0, 8>(wl + OFF_T2 + (li - 1) * SZ_HID, nullptr, dz, nullptr, acc, [&](int jb, f32x16 c) {
-            const f32x16 act = load_block(S, srow + 32 * jb);
+        const int wrow = W_DZ + (li - 1) * 256;
+        load_mask(S, li - 1, mk);
+        layer_mfma<8, 0, 8, PFK>(wl + OFF_T2 + (li - 1) * SZ_HID, nullptr, dz, nullptr, acc, [](int) { return 0; },
+                                 [&](int jb, int q, f32x4 c, int) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = act[r] > 0.f ? c[r] : 0.f;
-            store_block(Wk, wrow + 32 * jb, c);
-            return c;
-        });
+                                     for (int t = 0; t < 4; ++t) c[t] = mask_bit(mk, jb, q, t) ? c[t] : 0.f;
+                                     store_slice(Wk, wrow + 32 * jb, q, c);
+                                     return c;
+                                 });
 #pragma unroll
         for (int b = 0; b < 8; ++b) dz[b] = acc[b];
     }
@@ -159,7 +161,8 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
     const int64_t tiles = ld / 32;
     const int64_t t_lo = tiles * chunk / T.chunks, t_hi = tiles * (chunk + 1) / T.chunks;
 
-    // global sources of this thread's staging slots
+    // global sources of this thread's staging slots: inside a tile the rows of an image are contiguous
+    // (128 B each), so slot u = row*8 + c4 is simply float4 number u of the row range: 1 KiB per wave-load
     const float *src[NLD];
     bool valid[NLD];
 #pragma unroll
@@ -167,11 +170,11 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
         const int u = i * 256 + tid, row = u >> 3, c4 = u & 7;
         if (row < JB * 32) {
             valid[i] = row < T.a_valid;
-            src[i] = work + (int64_t)(T.a_row0 + (valid[i] ? row : 0)) * ld + 4 * c4;
+            src[i] = work + (int64_t)(T.a_row0 + (valid[i] ? row : 0)) * 32 + 4 * c4;
         } else {
             const int rb = row - JB * 32;
             valid[i] = rb < T.b_valid;
-            src[i] = saved + (int64_t)(T.b_row0 + (valid[i] ? rb : 0)) * ld + 4 * c4;
+            src[i] = saved + (int64_t)(T.b_row0 + (valid[i] ? rb : 0)) * 32 + 4 * c4;
         }
     }
     f32x16 acc[JW][KW];
@@ -189,8 +192,8 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
     auto load_tile = [&](int64_t t) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            stage[i] = ldg4(src[i] + t * 32);
-            if (!valid[i]) stage[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool is_a = (i * 256 + tid) < JB * 32 * 8;
+            stage[i] = ldg4(src[i] + t * (is_a ? W_ROWS * 32 : SAVED_ROWS * 32));   // consumed one tile later
         }
     };
     if (t_lo < t_hi) load_tile(t_lo);
@@ -199,7 +202,9 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int u = i * 256 + tid, row = u >> 3, c4 = u & 7;
-            *reinterpret_cast<f32x4 *>(lds + row * LROW + 4 * c4) = stage[i];
+            // rows beyond the real operand (padding of the heads) are zeroed here, not at load time, so
+            // that the loads stay in flight under the previous tile's MFMAs
+            *reinterpret_cast<f32x4 *>(lds + row * LROW + 4 * c4) = valid[i] ? stage[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
         if (t + 1 < t_hi) load_tile(t + 1);    // in flight under the MFMAs below
@@ -311,7 +316,9 @@ static DwPlan make_plan(int64_t ld) {
     add(5, W_DSIG, 1, S_H + 256 * 7, 256, PARAM_SIGMA_W, 0, 256, PARAM_SIGMA_B);     // sigma
     P.n_tasks = n;
     // chunks proportional to MFMA work so that every workgroup costs the same and the grid is <= 256 (one per CU)
-    static const int base[6] = {24, 6, 12, 2, 2, 3};
+    // cost per 32-point tile ~ MFMA cycles + ~1.5k cycles of staging/barriers (measured: the small tasks were
+    // the critical path when sized by MFMA work alone)
+    static const int base[6] = {23, 8, 13, 4, 4, 5};
     const int64_t tiles = ld / 32;
     int wg = 0, off = 0;
     for (int i = 0; i < n; ++i) {
@@ -353,7 +360,6 @@ int nerfmi_nerf_backward_rays(const float *packed, const float *rays, const floa
     NERFMI_REQUIRE(packed && saved && grad_out && grad_params && workspace, "nerf_backward_rays: null pointer");
     const int64_t n_points = (int64_t)n_rays * n_per_ray;
     const int64_t ld = pad_points(n_points);
-    NERFMI_REQUIRE(5 * ld * 4 < ((int64_t)1 << 32), "nerf_backward_rays: n_points too large for 32-bit lane offsets");
     GradPtrs G;
     for (int i = 0; i < N_PARAMS; ++i) {
         NERFMI_REQUIRE(grad_params[i], "nerf_backward_rays: grad_params[%d] is null", i);

@@ -97,15 +97,21 @@ constexpr LayerDesc LAYERS[NL_FWD] = {
 };
 constexpr int PARAM_SIGMA_W = 20, PARAM_SIGMA_B = 21, PARAM_RGB_W = 22, PARAM_RGB_B = 23;
 
-// Activations kept for training, all as [row][point] (row-major over points,
-// n_points padded to 32): rows of S_* below.  Post-ReLU values (nn.ReLU(True)
-// saves its output, nerf.py:68).
+// Activations kept for training: tile-major [tile of 32 points][row][32] images
+// (mlp_core.h RowImage), n_points padded to 32: rows of S_* below.  Post-ReLU
+// values (nn.ReLU(True) saves its output, nerf.py:68).
 constexpr int S_EMB = 0;        // 64 rows: xyz embedding (row 63 = 0)
 constexpr int S_H = 64;         // 8 x 256 rows: h1..h8
 constexpr int S_FINAL = S_H + 8 * 256;   // 256 rows: xyz_encoding_final output
 constexpr int S_DEMB = S_FINAL + 256;    // 32 rows: dir embedding (rows 27..31 = 0)
 constexpr int S_DIRH = S_DEMB + 32;      // 128 rows: dir_encoding output
 constexpr int S_RGB = S_DIRH + 128;      // 3 rows (+1 pad): sigmoid output
-constexpr int SAVED_ROWS = S_RGB + 4;
+// ReLU sign bits, 9 x 8 rows (= 9 x 1 KiB per tile): for layer m (0..7 = xyz_encoding_1..8, 8 =
+// dir_encoding) lane l of the owning wave keeps 4 dwords at row S_MASK + 8*m, float offset 4*l:
+// bit 16*(jb&1) + r of dword jb>>1 is (output register r of block jb > 0).  The backward chain uses
+// the same lane/register map, so it masks with one 16-byte load per layer instead of re-reading the
+// fp32 activations (32x less traffic and no HBM-latency load in its in-order vmcnt queue).
+constexpr int S_MASK = S_RGB + 4;
+constexpr int SAVED_ROWS = S_MASK + 9 * 8;
 
 }  // namespace nerfmi
