@@ -40,13 +40,13 @@ def parse():
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--batch", type=int, default=1024, help="rays per rank per step (configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work in the bounded cpu_baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(mode, n_rays):
-    """numpy oracle (kind 'port') on the host cores, bounded sample."""
-    import numpy as np
+def cpu_baseline(mode, budget_s=12.0, chunk=256, max_rays=8192):
+    """numpy oracle (kind 'port') on the host cores: chunks of `chunk` rays of the same workload until
+    ~budget_s seconds of CPU work are done (bounded sample; the chunking only bounds memory)."""
     from nerf_siren_amd import synth
     from oracle import nerf_oracle as O
     try:
@@ -55,21 +55,26 @@ def cpu_baseline(mode, n_rays):
     except Exception:
         cores = os.cpu_count() or 1
     params = [synth.nerf_params(1, False), synth.nerf_params(2, False)]
-    rays = synth.blender_rays(n_rays, seed=123)
-    t0 = time.perf_counter()
-    if mode == "infer":
-        O.render_rays(params, rays, 64, False, 0.0, 0.0, 64, True, True)
-    else:
-        rng = {"perturb_rand": synth.hash_uniform((n_rays, 64), 1), "noise_coarse": synth.hash_normal((n_rays, 64), 2),
-               "u": synth.hash_uniform((n_rays, 64), 3), "noise_fine": synth.hash_normal((n_rays, 128), 4)}
-        res = O.render_rays(params, rays, 64, False, 1.0, 1.0, 64, True, False, rng=rng, keep=True)
-        tgt = synth.hash_uniform((n_rays, 3), 5)
-        g = {"rgb_coarse": 2 * (res["rgb_coarse"] - tgt) / (3 * n_rays),
-             "rgb_fine": 2 * (res["rgb_fine"] - tgt) / (3 * n_rays)}
-        O.render_rays_backward(params, res, g, True)
-    dt = time.perf_counter() - t0
-    return {"value": n_rays * 192 / dt, "unit": "ray-samples/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n_rays} rays x (64+128) samples, {mode} step, numpy oracle, {dt:.1f} s"}
+    done, dt, i = 0, 0.0, 0
+    while dt < budget_s and done < max_rays:
+        n = chunk
+        rays = synth.blender_rays(n, seed=123 + i)
+        t0 = time.perf_counter()
+        if mode == "infer":
+            O.render_rays(params, rays, 64, False, 0.0, 0.0, 64, True, True)
+        else:
+            rng = {"perturb_rand": synth.hash_uniform((n, 64), 1), "noise_coarse": synth.hash_normal((n, 64), 2),
+                   "u": synth.hash_uniform((n, 64), 3), "noise_fine": synth.hash_normal((n, 128), 4)}
+            res = O.render_rays(params, rays, 64, False, 1.0, 1.0, 64, True, False, rng=rng, keep=True)
+            tgt = synth.hash_uniform((n, 3), 5)
+            g = {"rgb_coarse": 2 * (res["rgb_coarse"] - tgt) / (3 * n), "rgb_fine": 2 * (res["rgb_fine"] - tgt) / (3 * n)}
+            O.render_rays_backward(params, res, g, True)
+        dt += time.perf_counter() - t0
+        done += n
+        i += 1
+    return {"value": done * 192 / dt, "unit": "ray-samples/s", "cores": int(cores), "kind": "port",
+            "sample": f"{done} rays x (64+128) samples in chunks of {chunk}, {mode} step "
+                      f"(fwd{'+bwd' if mode == 'train' else ''}), numpy oracle, {dt:.1f} s"}
 
 
 def main():
@@ -133,7 +138,7 @@ def main():
             res = render_rays(models, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, True, False)
             t = tgt_pool[i % n_pool]
             loss = ((res["rgb_coarse"] - t) ** 2).mean() + ((res["rgb_fine"] - t) ** 2).mean()   # losses.py:15-20
-            opt.zero_grad(set_to_none=False)
+            opt.zero_grad(set_to_none=True)
             loss.backward()
             reducer.all_reduce()
             opt.step()
@@ -183,8 +188,7 @@ def main():
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": kern_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
-            n_cpu = args.cpu_rays or (96 if train else 256)
-            out["cpu_baseline"] = cpu_baseline(args.mode, n_cpu)
+            out["cpu_baseline"] = cpu_baseline(args.mode, budget_s=args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -71,6 +71,20 @@ PARAM_SHAPES = ([(256, 63), (256,)] + [(256, 256), (256,)] * 3 + [(256, 319), (2
                 + [(256, 256), (256,), (128, 283), (128,), (1, 256), (1,), (3, 128), (3,)])
 
 
+PARAM_SIZES = [int(torch.Size(s).numel()) for s in PARAM_SHAPES]
+PARAM_NUMEL = sum(PARAM_SIZES)          # 595 844
+
+
+def flat_views(flat):
+    """The 24 parameter-shaped views of one contiguous buffer (state_dict order): a model's gradient is
+    ONE allocation, so the data-parallel all-reduce needs no flatten/unflatten copies."""
+    out, off = [], 0
+    for shape, n in zip(PARAM_SHAPES, PARAM_SIZES):
+        out.append(flat[off:off + n].view(shape))
+        off += n
+    return out
+
+
 def _ptr_array(tensors):
     arr = (C.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
@@ -124,7 +138,7 @@ def nerf_backward_rays(packed, rays, z, saved, grad_out, grads=None):
     n, p = z.shape
     grad_out = _req(grad_out, "grad_out", (n * p, 4))
     if grads is None:
-        grads = [torch.empty(s, device=rays.device, dtype=torch.float32) for s in PARAM_SHAPES]
+        grads = flat_views(torch.empty(PARAM_NUMEL, device=rays.device, dtype=torch.float32))
     ws = torch.empty(_lib.lib().nerfmi_nerf_backward_workspace_floats(n * p), device=rays.device,
                      dtype=torch.float32)
     check(_lib.lib().nerfmi_nerf_backward_rays(ptr(packed), ptr(rays), ptr(z), n, p, ptr(saved), ptr(grad_out),

@@ -14,27 +14,55 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
+    """all-reduce(mean) of the models' gradients with as few collectives as storage allows.
+
+    The HIP backward writes a model's 24 gradients into one contiguous buffer (ops.flat_views), so
+    after loss.backward() every p.grad of a NeRF is a view of the same base tensor: that base is
+    all-reduced directly (one collective per model, no copies).  Gradients that do not share a base
+    (foreign modules, accumulated grads) are flattened into a scratch buffer instead.
+    """
+
     def __init__(self, models, world_size: int | None = None, group=None):
-        self.params = [p for m in models for p in m.parameters() if p.requires_grad]
+        self.models = list(models)
+        self.params = [p for m in self.models for p in m.parameters() if p.requires_grad]
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.group = group
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        self.flat = None
+
+    def _bases(self):
+        bases, loose = [], []
+        for m in self.models:
+            ps = [p for p in m.parameters() if p.requires_grad and p.grad is not None]
+            if not ps:
+                continue
+            b = ps[0].grad._base
+            n = sum(p.grad.numel() for p in ps)
+            if b is not None and b.dim() == 1 and b.numel() == n and all(p.grad._base is b for p in ps):
+                bases.append(b)
+            else:
+                loose.extend(ps)
+        return bases, loose
 
     def zero_(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
 
     def all_reduce(self):
-        """mean over ranks, in place (DDP semantics)."""
+        """mean over ranks, in place (DDP semantics). Returns the reduced buffers."""
+        bases, loose = self._bases()
         if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.mul_(1.0 / self.world)
-        return self.flat
+            for b in bases:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+                b.mul_(1.0 / self.world)
+            if loose:
+                flat = torch.cat([p.grad.reshape(-1) for p in loose])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                flat.mul_(1.0 / self.world)
+                off = 0
+                for p in loose:
+                    p.grad.copy_(flat[off:off + p.grad.numel()].view_as(p.grad))
+                    off += p.grad.numel()
+        return bases
 
 
 def shard_rays(n_total: int, rank: int, world: int):

@@ -40,9 +40,15 @@ def _worker(rank, world, port, q):
     red = FlatGradAllReduce(models, world)
     red.zero_()
     _loss(models, rays[lo:hi]).backward()
-    flat = red.all_reduce().clone()
-    # every p.grad is a view into the flat buffer
-    assert all(p.grad.data_ptr() >= red.flat.data_ptr() for p in red.params)
+    # model 1: gradients living in one flat base (what the HIP backward produces); model 0: loose tensors
+    flat1 = torch.cat([p.grad.reshape(-1) for p in models[1].parameters()])
+    off = 0
+    for p in models[1].parameters():
+        p.grad = flat1[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    bases = red.all_reduce()
+    assert len(bases) == 1 and bases[0] is flat1
+    flat = torch.cat([p.grad.reshape(-1) for m in models for p in m.parameters()])
     q.put((rank, flat))
     dist.barrier()
     dist.destroy_process_group()
