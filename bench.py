@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 FLOP_FULL = 1_186_816        # NeRF full forward per sample
 FLOP_SIGMA = 982_528         # sigma-only forward per sample
 FLOP_TRAIN = 3_489_024       # fwd + dW + dX per sample
+FLOP_SIREN = 1_053_696       # FiLM-SIREN full forward per sample (+2 304 sin)
 PEAK_F32_MFMA = 157.3        # TFLOP/s dense (MI355X_MICROARCH.md)
 
 
@@ -39,6 +40,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--batch", type=int, default=1024, help="rays per rank per step (configs[1])")
+    ap.add_argument("--field", choices=["nerf", "siren"], default="nerf",
+                    help="nerf = the reference's live 8x256 ReLU NeRF; siren = its FiLM-SIREN field (inference only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work in the bounded cpu_baseline sample")
     return ap.parse_args()
@@ -99,9 +102,19 @@ def main():
 
     B = args.batch
     models = []
+    siren = args.field == "siren"
+    if siren and args.mode != "infer":
+        raise SystemExit("--field siren supports --mode infer only (the reference never trains its SIREN field)")
     for seed in (1, 2):
-        m = NeRF()
-        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
+        if siren:
+            from nerf_siren_amd import SemanticNeRF, SirenField
+            sm = SemanticNeRF()
+            sm.load_state_dict({k: torch.from_numpy(v) for k, v in synth.siren_params(seed).items()})
+            m = SirenField(sm, torch.from_numpy(synth.hash_normal((1, 2304), 10 + seed)),
+                           torch.from_numpy(synth.hash_normal((1, 2304), 20 + seed)))
+        else:
+            m = NeRF()
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
         models.append(m.to(dev))
     emb = [Embedding(3, 10), Embedding(3, 4)]
     # a pool of batches resident in HBM before the timed region (each rank its own shard of rays)
@@ -131,6 +144,20 @@ def main():
 
     import nerf_siren_amd.rendering as R
     R.ops.nerf_forward_rays = timed_fwd
+    if siren:
+        orig_siren = ops.siren_forward_rays
+
+        def timed_siren(packed, rays, z, freq, phase, rpc, sigma_only=False):
+            if z.shape[1] != 128:
+                return orig_siren(packed, rays, z, freq, phase, rpc, sigma_only)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = orig_siren(packed, rays, z, freq, phase, rpc, sigma_only)
+            b.record()
+            ev.append((a, b))
+            return out
+
+        ops.siren_forward_rays = timed_siren
 
     def step(i):
         rays = rays_pool[i % n_pool]
@@ -166,7 +193,7 @@ def main():
     dt = float(tmax.item())
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
-    flops_per_launch = B * 128 * FLOP_FULL
+    flops_per_launch = B * 128 * (FLOP_SIREN if siren else FLOP_FULL)
     achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
 
     if rank == 0:
@@ -178,16 +205,17 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: Blender-lego 400x400 rays, N_samples=64 N_importance=64, "
-                                   f"batch_size={B} rays/GPU, NeRF 8x256 coarse+fine, mode={args.mode}",
+                                   f"batch_size={B} rays/GPU, {'FiLM-SIREN 9x256' if siren else 'NeRF 8x256'} coarse+fine, "
+                                   f"mode={args.mode}",
                        "rays_per_gpu": B, "samples_per_ray": 192, "mode": args.mode,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "rays_per_s": world * B * args.steps / dt,
-            "roofline": {"bound": "mfma", "kernel": "nerf_forward_kernel (fine MLP, 128 samples/ray)",
+            "roofline": {"bound": "mfma", "kernel": ("siren_forward_kernel" if siren else "nerf_forward_kernel") + " (fine MLP, 128 samples/ray)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA, "traffic": None,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": kern_ms},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not siren:
             out["cpu_baseline"] = cpu_baseline(args.mode, budget_s=args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -85,6 +85,25 @@ int nerfmi_nerf_backward_rays(const float *packed, const float *rays, const floa
                               const float *saved, const float *grad_out, float *const *grad_params,
                               float *workspace, nerfmi_stream_t stream);
 
+/* ---- a7: FiLM-SIREN field -- models/nerf.py:142-151 (FiLMLayer), :159-216 (SemanticNeRF) -----------
+ * params: HOST array of 22 DEVICE pointers in state_dict order
+ *   network.{0..7}.layer.{weight,bias}, final_layer.{weight,bias},
+ *   color_layer_sine.layer.{weight,bias}, color_layer_linear.0.{weight,bias}
+ * forward_with_frequencies_phase_shifts(input, frequencies, phase_shifts, ray_directions) (:201-216):
+ *   points (n_points,3), ray_directions (n_points,3), frequencies / phase_shifts (n_cond, 9*256) where
+ *   consecutive groups of points_per_cond points share one conditioning row (the reference's (Bz,Np,3)
+ *   input flattened: points_per_cond = Np).  out (n_points,4) [rgb,sigma] or (n_points,1) sigma_only. */
+size_t nerfmi_siren_packed_floats(void);
+int nerfmi_siren_pack(const float *const *params, float *packed, nerfmi_stream_t stream);
+int nerfmi_siren_forward_points(const float *packed, const float *points, const float *ray_directions,
+                                const float *frequencies, const float *phase_shifts, int64_t n_points,
+                                int64_t points_per_cond, int sigma_only, float *out, nerfmi_stream_t stream);
+/* The same field fused behind the ray sampler (inference() head, rendering.py:131-159, with raw xyz / d
+ * instead of embeddings): xyz = o + d*z per sample; rays_per_cond consecutive rays share a conditioning row. */
+int nerfmi_siren_forward_rays(const float *packed, const float *rays, const float *z, const float *frequencies,
+                              const float *phase_shifts, int n_rays, int n_per_ray, int64_t rays_per_cond,
+                              int sigma_only, float *out, nerfmi_stream_t stream);
+
 /* ---- a8: compositing -- models/rendering.py:162-190 ----------------------
  * field: (n_rays,n_per_ray,4) [rgb,sigma] or, when sigma_only, (n_rays,n_per_ray)
  * sigma (the weights_only branch :179-180: only weights/opacity are produced).

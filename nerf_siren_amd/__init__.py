@@ -12,7 +12,7 @@ def __getattr__(name):
     if name in ("render_rays", "sample_pdf"):
         from . import rendering
         return getattr(rendering, name)
-    if name in ("Embedding", "NeRF"):
+    if name in ("Embedding", "NeRF", "SemanticNeRF", "FiLMLayer", "SirenField"):
         from . import nerf
         return getattr(nerf, name)
     if name == "searchsorted":

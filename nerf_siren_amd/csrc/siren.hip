@@ -1,0 +1,200 @@
+// FiLM-SIREN field forward for gfx950 (MI355X): FiLMLayer (models/nerf.py:142-151)
+// and SemanticNeRF.forward_with_frequencies_phase_shifts (models/nerf.py:201-216).
+//
+// Same register-resident scheme as the NeRF MLP (mlp_core.h): a wave owns 32
+// points, the 256-wide hidden state lives in accumulator registers through all
+// nine FiLM layers, weights stream from L2 as packed 1 KiB MFMA fragments.  The
+// FiLM epilogue  sin(freq * (W h + b) + phase)  runs on the VALU in four slices
+// per 32-unit block, placed between the next block's MFMAs (layer_mfma), so the
+// 2304 sines per point execute in the shadow of the matrix pipe.
+#include "mlp_core.h"
+
+namespace nerfmi {
+
+// packed SIREN image (floats)
+constexpr int SOFF_L1 = 0;                          // 8 jb x 1 kb   (3 valid input columns)
+constexpr int SSZ_L1 = 8 * 1 * 1024;
+constexpr int SOFF_L2 = SOFF_L1 + SSZ_L1;           // 7 hidden layers, 8 x 8 each
+constexpr int SOFF_COLOR = SOFF_L2 + 7 * SZ_HID;    // 8 jb x 9 kb   ([dir 3 | hidden 256], nerf.py:213)
+constexpr int SSZ_COLOR = 8 * 9 * 1024;
+constexpr int SOFF_BIAS = SOFF_COLOR + SSZ_COLOR;   // 9 x 256 (network.0..7, color_layer_sine)
+constexpr int SOFF_W_SIGMA = SOFF_BIAS + 9 * 256;   // 256
+constexpr int SOFF_B_SIGMA = SOFF_W_SIGMA + 256;    // 1 (+3)
+constexpr int SOFF_W_RGB = SOFF_B_SIGMA + 4;        // 3 x 256
+constexpr int SOFF_B_RGB = SOFF_W_RGB + 768;        // 3 (+1)
+constexpr int SIREN_PACKED_FLOATS = SOFF_B_RGB + 4;
+constexpr int SIREN_N_PARAMS = 22;  // network.{0..7}.layer.{weight,bias}, final_layer.*, color_layer_sine.layer.*, color_layer_linear.0.*
+
+struct SirenParamPtrs {
+    const float *p[SIREN_N_PARAMS];
+};
+
+__global__ void siren_pack_kernel(SirenParamPtrs P, float *__restrict__ packed) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < SIREN_PACKED_FLOATS; idx += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (idx < SOFF_BIAS) {
+            int layer, KB, in_f, rel;
+            if (idx < SOFF_L2) { layer = 0; KB = 1; in_f = 3; rel = idx; }
+            else if (idx < SOFF_COLOR) { layer = 1 + (idx - SOFF_L2) / SZ_HID; KB = 8; in_f = 256; rel = (idx - SOFF_L2) % SZ_HID; }
+            else { layer = 8; KB = 9; in_f = 259; rel = idx - SOFF_COLOR; }
+            const int t = rel & 3, lane = (rel >> 2) & 63, g = rel >> 8;
+            const int q = g & 3, kb = (g >> 2) % KB, jb = (g >> 2) / KB;
+            const int row = 32 * jb + (lane & 31);
+            const int kc = 32 * kb + 8 * q + 4 * (lane >> 5) + t;
+            int col = -1;
+            if (layer == 0) { if (kc < 3) col = kc; }
+            else if (layer < 8) col = kc;
+            else { if (kc < 32) { if (kc < 3) col = kc; } else col = 3 + (kc - 32); }
+            const int pi = (layer < 8) ? 2 * layer : 18;     // color_layer_sine.layer.weight = param 18
+            if (col >= 0) v = P.p[pi][row * in_f + col];
+        } else if (idx < SOFF_W_SIGMA) {
+            const int s = idx - SOFF_BIAS, layer = s >> 8;
+            v = P.p[layer < 8 ? 2 * layer + 1 : 19][s & 255];
+        } else if (idx < SOFF_B_SIGMA) v = P.p[16][idx - SOFF_W_SIGMA];
+        else if (idx < SOFF_W_RGB) v = (idx == SOFF_B_SIGMA) ? P.p[17][0] : 0.f;
+        else if (idx < SOFF_B_RGB) v = P.p[20][idx - SOFF_W_RGB];
+        else v = (idx - SOFF_B_RGB < 3) ? P.p[21][idx - SOFF_B_RGB] : 0.f;
+        packed[idx] = v;
+    }
+}
+
+template <bool FROM_RAYS, bool SIGMA_ONLY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__ rays, const float *__restrict__ z,
+                     const float *__restrict__ pts, const float *__restrict__ dirs, const float *__restrict__ freq,
+                     const float *__restrict__ phase, int64_t n_points, int n_per_ray, int64_t points_per_cond,
+                     float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t p0 = wave * 32;
+    if (p0 >= n_points) return;
+    const int64_t praw = p0 + (lane & 31);
+    const bool ok = praw < n_points;
+    const int64_t p = ok ? praw : n_points - 1;
+
+    float x[3], d[3];
+    if (FROM_RAYS) {
+        const float *rr = rays + (p / n_per_ray) * 8;
+        const float zz = z[p];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            x[c] = __fadd_rn(rr[c], __fmul_rn(rr[3 + c], zz));      // rendering.py:224-225
+            d[c] = rr[3 + c];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { x[c] = pts[p * 3 + c]; d[c] = dirs ? dirs[p * 3 + c] : 0.f; }
+    }
+    const float warp = 2.0f / 51.0f;                                 // UniformBoxWarp(51), nerf.py:134-140, :193
+    f32x16 e[1], de[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = 8 * (r >> 2) + 4 * half + (r & 3);
+        e[0][r] = (c < 3) ? __fmul_rn(x[c < 3 ? c : 0], warp) : 0.f;
+        de[0][r] = (c < 3) ? d[c < 3 ? c : 0] : 0.f;
+    }
+    // this lane's conditioning row (frequencies, phase_shifts are (n_cond, 9*256))
+    const float *fq = freq + (p / points_per_cond) * 2304 + 4 * half;
+    const float *ph = phase + (p / points_per_cond) * 2304 + 4 * half;
+    auto film_epi = [&](int layer) {
+        return [fq, ph, layer](int jb, int q, f32x4 c, int) {
+            const f32x4 f = ldg4(fq + 256 * layer + 32 * jb + 8 * q);
+            const f32x4 s = ldg4(ph + 256 * layer + 32 * jb + 8 * q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float fr = __fadd_rn(__fmul_rn(f[t], 15.0f), 30.0f);          // nerf.py:202
+                c[t] = sinf(__fadd_rn(__fmul_rn(fr, c[t]), s[t]));                  // nerf.py:151
+            }
+            return c;
+        };
+    };
+    auto no_pre = [](int) { return 0; };
+    const float *wl = packed + lane * 4;
+    const float *bias = packed + SOFF_BIAS + 4 * half;
+    f32x16 h[8], acc[8];
+    layer_mfma<1, 0, 8>(wl + SOFF_L1, bias, e, nullptr, acc, no_pre, film_epi(0));
+#pragma unroll
+    for (int b = 0; b < 8; ++b) h[b] = acc[b];
+    for (int l = 1; l < 8; ++l) {
+        layer_mfma<8, 0, 8>(wl + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, film_epi(l));
+#pragma unroll
+        for (int b = 0; b < 8; ++b) h[b] = acc[b];
+    }
+    const float sigma = dot_blocks<8>(h, packed + SOFF_W_SIGMA + 4 * half) + packed[SOFF_B_SIGMA];   // nerf.py:212
+    if (SIGMA_ONLY) {
+        if (ok && half == 0) out[p] = sigma;
+        return;
+    }
+    layer_mfma<1, 8, 8>(wl + SOFF_COLOR, bias + 256 * 8, de, h, acc, no_pre, film_epi(8));            // nerf.py:213
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float pre = dot_blocks<8>(acc, packed + SOFF_W_RGB + 256 * c + 4 * half) + packed[SOFF_B_RGB + c];
+        rgb[c] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-pre)));                                         // nerf.py:214
+    }
+    if (ok && half == 0) {
+        float4 o;
+        o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2]; o.w = sigma;
+        reinterpret_cast<float4 *>(out)[p] = o;
+    }
+}
+
+}  // namespace nerfmi
+
+using namespace nerfmi;
+
+extern "C" {
+
+size_t nerfmi_siren_packed_floats(void) { return (size_t)SIREN_PACKED_FLOATS; }
+
+int nerfmi_siren_pack(const float *const *params, float *packed, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(params && packed, "siren_pack: null pointer");
+    SirenParamPtrs P;
+    for (int i = 0; i < SIREN_N_PARAMS; ++i) {
+        NERFMI_REQUIRE(params[i], "siren_pack: params[%d] is null", i);
+        P.p[i] = params[i];
+    }
+    hipLaunchKernelGGL(siren_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, P, packed);
+    return check_launch("siren_pack");
+}
+
+int nerfmi_siren_forward_points(const float *packed, const float *points, const float *ray_directions,
+                                const float *frequencies, const float *phase_shifts, int64_t n_points,
+                                int64_t points_per_cond, int sigma_only, float *out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_points >= 0 && points_per_cond >= 1, "siren_forward_points: bad sizes");
+    if (n_points == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(packed && points && frequencies && phase_shifts && out, "siren_forward_points: null pointer");
+    NERFMI_REQUIRE(sigma_only || ray_directions, "siren_forward_points: ray_directions required for the colour branch");
+    const int64_t waves = (n_points + 31) / 32;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (sigma_only)
+        hipLaunchKernelGGL((siren_forward_kernel<false, true>), grid, block, 0, st, packed, nullptr, nullptr, points,
+                           ray_directions, frequencies, phase_shifts, n_points, 1, points_per_cond, out);
+    else
+        hipLaunchKernelGGL((siren_forward_kernel<false, false>), grid, block, 0, st, packed, nullptr, nullptr, points,
+                           ray_directions, frequencies, phase_shifts, n_points, 1, points_per_cond, out);
+    return check_launch("siren_forward_points");
+}
+
+int nerfmi_siren_forward_rays(const float *packed, const float *rays, const float *z, const float *frequencies,
+                              const float *phase_shifts, int n_rays, int n_per_ray, int64_t rays_per_cond,
+                              int sigma_only, float *out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && rays_per_cond >= 1, "siren_forward_rays: bad sizes");
+    const int64_t n_points = (int64_t)n_rays * n_per_ray;
+    if (n_points == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(packed && rays && z && frequencies && phase_shifts && out, "siren_forward_rays: null pointer");
+    const int64_t waves = (n_points + 31) / 32;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (sigma_only)
+        hipLaunchKernelGGL((siren_forward_kernel<true, true>), grid, block, 0, st, packed, rays, z, nullptr, nullptr,
+                           frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out);
+    else
+        hipLaunchKernelGGL((siren_forward_kernel<true, false>), grid, block, 0, st, packed, rays, z, nullptr, nullptr,
+                           frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out);
+    return check_launch("siren_forward_rays");
+}
+
+}  // extern "C"

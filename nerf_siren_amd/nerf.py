@@ -80,3 +80,118 @@ class NeRF(nn.Module):
             from .rendering import EmbeddedField
             return EmbeddedField.apply(self, x, bool(sigma_only), *self.param_list())
         return ops.nerf_forward_embedded(self.packed(), x, sigma_only)
+
+
+# ---------------------------------------------------------------------------------------------
+# FiLM-SIREN field (models/nerf.py:126-216)
+# ---------------------------------------------------------------------------------------------
+def frequency_init(freq):
+    """models/nerf.py:126-132."""
+    def init(m):
+        with torch.no_grad():
+            if isinstance(m, nn.Linear):
+                num_input = m.weight.size(-1)
+                b = (6 / num_input) ** 0.5 / freq
+                m.weight.uniform_(-b, b)
+    return init
+
+
+def first_layer_film_sine_init(m):
+    """models/nerf.py:153-157."""
+    with torch.no_grad():
+        if isinstance(m, nn.Linear):
+            num_input = m.weight.size(-1)
+            m.weight.uniform_(-1 / num_input, 1 / num_input)
+
+
+class UniformBoxWarp(nn.Module):
+    """models/nerf.py:134-140 (applied inside the kernel; kept for attribute parity)."""
+
+    def __init__(self, sidelength):
+        super().__init__()
+        self.scale_factor = 2 / sidelength
+
+
+class FiLMLayer(nn.Module):
+    """FiLMLayer(input_dim, hidden_dim) -- models/nerf.py:142-151: sin(freq * Linear(x) + phase_shift).
+    Parameter holder: the arithmetic of all nine layers runs in one fused HIP kernel."""
+
+    def __init__(self, input_dim, hidden_dim):
+        super().__init__()
+        self.layer = nn.Linear(input_dim, hidden_dim)
+
+
+class SemanticNeRF(nn.Module):
+    """SemanticNeRF(input_dim=2, z_dim=100, hidden_dim=256, output_dim=1, device=None) --
+    models/nerf.py:159-216, the pi-GAN style FiLM-SIREN field ("TALLSIREN" + UniformBoxWarp(51)).
+
+    Same parameter names/shapes/init as the reference (529 156 parameters).
+    forward_with_frequencies_phase_shifts(input (Bz,Np,3), frequencies (Bz,9*256), phase_shifts (Bz,9*256),
+    ray_directions (Bz,Np,3)) -> (Bz,Np,4) [rgb, sigma].
+    """
+
+    def __init__(self, input_dim=2, z_dim=100, hidden_dim=256, output_dim=1, device=None):
+        super().__init__()
+        if hidden_dim != 256:
+            raise NotImplementedError("the gfx950 SIREN kernel is specialised for hidden_dim=256 (the reference default)")
+        self.device = device
+        self.input_dim, self.z_dim, self.hidden_dim, self.output_dim = input_dim, z_dim, hidden_dim, output_dim
+        self.network = nn.ModuleList([FiLMLayer(3, hidden_dim)] + [FiLMLayer(hidden_dim, hidden_dim) for _ in range(7)])
+        self.final_layer = nn.Linear(hidden_dim, 1)
+        self.color_layer_sine = FiLMLayer(hidden_dim + 3, hidden_dim)
+        self.color_layer_linear = nn.Sequential(nn.Linear(hidden_dim, 3))
+        self.network.apply(frequency_init(25))
+        self.final_layer.apply(frequency_init(25))
+        self.color_layer_sine.apply(frequency_init(25))
+        self.color_layer_linear.apply(frequency_init(25))
+        self.network[0].apply(first_layer_film_sine_init)
+        self.gridwarper = UniformBoxWarp(51)
+        self._packed = None
+        self._packed_key = None
+
+    def param_list(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in ops.SIREN_PARAM_ORDER]
+
+    def packed(self):
+        ps = self.param_list()
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._packed is None or key != self._packed_key or self._packed.device != ps[0].device:
+            self._packed = ops.siren_pack(ps)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, input, z, ray_directions, **kwargs):
+        # the reference calls self.mapping_network, which it never defines (nerf.py:185 is commented out)
+        raise AttributeError("'SemanticNeRF' object has no attribute 'mapping_network' (models/nerf.py:185, :198); "
+                             "use forward_with_frequencies_phase_shifts")
+
+    def forward_with_frequencies_phase_shifts(self, input, frequencies, phase_shifts, ray_directions, **kwargs):
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if input.requires_grad:
+                raise NotImplementedError("gradients w.r.t. SIREN inputs are not implemented")
+        bz, npts = input.shape[0], input.shape[1]
+        out = ops.siren_forward_points(self.packed(), input.reshape(-1, 3).contiguous(),
+                                       ray_directions.reshape(-1, 3).contiguous(),
+                                       frequencies.reshape(bz, -1).contiguous(), phase_shifts.reshape(bz, -1).contiguous(),
+                                       npts)
+        return out.view(bz, npts, 4)
+
+
+class SirenField(nn.Module):
+    """Adapter that lets the FiLM-SIREN field be rendered by render_rays() (the
+    reference's SemanticNeRF signature differs from NeRF.forward(x, sigma_only), so it cannot be passed to
+    render_rays unchanged).  One conditioning row (frequencies, phase_shifts) for all rays."""
+
+    def __init__(self, model: SemanticNeRF, frequencies=None, phase_shifts=None):
+        super().__init__()
+        self.model = model
+        h = 9 * model.hidden_dim
+        self.frequencies = nn.Parameter(torch.zeros(1, h) if frequencies is None else frequencies.reshape(1, h).clone(),
+                                        requires_grad=False)
+        self.phase_shifts = nn.Parameter(torch.zeros(1, h) if phase_shifts is None else phase_shifts.reshape(1, h).clone(),
+                                         requires_grad=False)
+
+    def field_rays(self, rays, z, sigma_only=False):
+        return ops.siren_forward_rays(self.model.packed(), rays, z, self.frequencies, self.phase_shifts,
+                                      rays.shape[0], sigma_only)

@@ -146,6 +146,53 @@ def nerf_backward_rays(packed, rays, z, saved, grad_out, grads=None):
     return grads
 
 
+# --------------------------------------------------------------------------- a7
+SIREN_PARAM_ORDER = ([f"network.{i}.layer.{k}" for i in range(8) for k in ("weight", "bias")]
+                     + ["final_layer.weight", "final_layer.bias", "color_layer_sine.layer.weight",
+                        "color_layer_sine.layer.bias", "color_layer_linear.0.weight", "color_layer_linear.0.bias"])
+SIREN_PARAM_SHAPES = ([(256, 3), (256,)] + [(256, 256), (256,)] * 7
+                      + [(1, 256), (1,), (256, 259), (256,), (3, 256), (3,)])
+
+
+def siren_pack(params, out=None):
+    ps = [_req(t.detach(), n, s) for n, s, t in zip(SIREN_PARAM_ORDER, SIREN_PARAM_SHAPES, params)]
+    n = _lib.lib().nerfmi_siren_packed_floats()
+    if out is None:
+        out = torch.empty(n, device=ps[0].device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_siren_pack(_ptr_array(ps), ptr(out), _stream(out)), "siren_pack")
+    return out
+
+
+def siren_forward_points(packed, points, dirs, freq, phase, points_per_cond, sigma_only=False):
+    points = _req(points, "points", (None, 3))
+    n = points.shape[0]
+    dirs = _req(dirs, "ray_directions", (n, 3)) if dirs is not None else None
+    freq = _req(freq, "frequencies", (None, 2304))
+    phase = _req(phase, "phase_shifts", (freq.shape[0], 2304))
+    if freq.shape[0] * points_per_cond < n:
+        raise ValueError("frequencies has too few rows for the points")
+    out = torch.empty((n, 1 if sigma_only else 4), device=points.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_siren_forward_points(ptr(packed), ptr(points), ptr(dirs), ptr(freq), ptr(phase), n,
+                                                 int(points_per_cond), int(bool(sigma_only)), ptr(out),
+                                                 _stream(points)), "siren_forward_points")
+    return out
+
+
+def siren_forward_rays(packed, rays, z, freq, phase, rays_per_cond, sigma_only=False):
+    rays = _req(rays, "rays", (None, 8))
+    z = _req(z, "z", (rays.shape[0], None))
+    n, p = z.shape
+    freq = _req(freq, "frequencies", (None, 2304))
+    phase = _req(phase, "phase_shifts", (freq.shape[0], 2304))
+    if freq.shape[0] * rays_per_cond < n:
+        raise ValueError("frequencies has too few rows for the rays")
+    out = torch.empty((n * p, 1 if sigma_only else 4), device=rays.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_siren_forward_rays(ptr(packed), ptr(rays), ptr(z), ptr(freq), ptr(phase), n, p,
+                                               int(rays_per_cond), int(bool(sigma_only)), ptr(out), _stream(rays)),
+          "siren_forward_rays")
+    return out
+
+
 # --------------------------------------------------------------------------- a8
 def composite(field, z, rays, noise=None, noise_std=0.0, white_back=False, sigma_only=False, want_weights=True):
     rays = _req(rays, "rays", (None, 8))

@@ -96,6 +96,9 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     S, F = int(N_samples), int(N_importance)
     model_coarse = models[0]
     train = torch.is_grad_enabled() and any(p.requires_grad for m in models for p in m.parameters())
+    if train and any(hasattr(m, "field_rays") for m in models):
+        raise NotImplementedError("training through the FiLM-SIREN field is not implemented (the reference never "
+                                  "wires SemanticNeRF into training either); call under torch.no_grad()")
 
     pr = _rng(rng, "perturb_rand", (N, S), dev, "rand") if perturb > 0 else None
     z = ops.sample_stratified(rays, S, use_disp, float(perturb), pr)
@@ -107,6 +110,10 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
 
     def full_pass(model, zz, key):
         noise = noise_for(key, zz.shape[1])
+        if hasattr(model, "field_rays"):                       # FiLM-SIREN adapter (nerf.SirenField): inference
+            field = model.field_rays(rays, zz, sigma_only=False)
+            weights, rgb, depth, opacity = ops.composite(field, zz, rays, noise, noise_std, white_back)
+            return rgb, depth, opacity, weights
         if train:
             rgb, depth, opacity, weights = FieldRender.apply(model, rays, zz, noise, float(noise_std),
                                                             bool(white_back), *model.param_list())
@@ -117,7 +124,10 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
 
     if test_time:
         # weights_only branch (rendering.py:227-231): sigma-only coarse MLP
-        sig = ops.nerf_forward_rays(model_coarse.packed(), rays, z, sigma_only=True)
+        if hasattr(model_coarse, "field_rays"):
+            sig = model_coarse.field_rays(rays, z, sigma_only=True)
+        else:
+            sig = ops.nerf_forward_rays(model_coarse.packed(), rays, z, sigma_only=True)
         weights_coarse, _, _, op = ops.composite(sig, z, rays, noise_for("noise_coarse", S), noise_std, white_back,
                                                  sigma_only=True)
         result = {"opacity_coarse": op}

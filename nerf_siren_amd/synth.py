@@ -147,3 +147,26 @@ def ndc_rays(n_rays: int, seed: int = 0, img_wh=(504, 378)) -> np.ndarray:
     d2 = 1 - o2
     rays = np.stack([o0, o1, o2, d0, d1, d2, np.zeros_like(o0), np.ones_like(o0)], -1)
     return rays.astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# FiLM-SIREN parameters, state_dict layout of models/nerf.py:159-191 (SemanticNeRF)
+# ---------------------------------------------------------------------------
+SIREN_SHAPES = (
+    [("network.0.layer", 256, 3)]
+    + [(f"network.{i}.layer", 256, 256) for i in range(1, 8)]
+    + [("final_layer", 1, 256), ("color_layer_sine.layer", 256, 259), ("color_layer_linear.0", 3, 256)]
+)
+
+
+def siren_params(seed: int = 0) -> dict:
+    """Parameters distributed like SemanticNeRF's init (nerf.py:126-132, :153-157, :187-191):
+    weights U(+-sqrt(6/in)/25) (first layer U(+-1/in)), biases nn.Linear default U(+-1/sqrt(in))."""
+    p = {}
+    for li, (name, fo, fi) in enumerate(SIREN_SHAPES):
+        wb = (1.0 / fi) if li == 0 else (np.sqrt(6.0 / fi) / 25.0)
+        w = (hash_uniform((fo, fi), seed * 1000 + 500 + 2 * li) * 2 - 1) * np.float32(wb)
+        b = (hash_uniform((fo,), seed * 1000 + 501 + 2 * li) * 2 - 1) * np.float32(1.0 / np.sqrt(fi))
+        p[name + ".weight"] = w.astype(np.float32)
+        p[name + ".bias"] = b.astype(np.float32)
+    return p

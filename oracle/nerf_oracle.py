@@ -401,3 +401,34 @@ def render_rays_backward(params, res, grads, white_back=False):
         g_out = np.concatenate([d_rgb, d_s[:, :, None]], -1).reshape(-1, 4)
         out.append(nerf_backward(params[0 if tag == "coarse" else 1], mcache, g_out))
     return out
+
+
+# ----------------------------------------------------------------------------
+# a7  FiLM-SIREN field: FiLMLayer (nerf.py:142-151) and
+#     SemanticNeRF.forward_with_frequencies_phase_shifts (nerf.py:201-216)
+# ----------------------------------------------------------------------------
+def film_layer(w, b, x, freq, phase):
+    """FiLMLayer.forward: sin(freq * (x W^T + b) + phase); freq/phase (Bz,H) broadcast over points."""
+    y = (x @ w.T + b).astype(F32)
+    arg = ((freq[:, None, :] * y).astype(F32) + phase[:, None, :]).astype(F32)
+    return np.sin(arg.astype(F64)).astype(F32)
+
+
+def siren_forward(p: dict, inp, frequencies, phase_shifts, ray_directions, sigma_only: bool = False):
+    """inp (Bz,Np,3), frequencies/phase_shifts (Bz, 9*256), ray_directions (Bz,Np,3) -> (Bz,Np,4) [rgb,sigma]."""
+    inp = np.asarray(inp, F32)
+    H = 256
+    fr = ((np.asarray(frequencies, F32) * F32(15)).astype(F32) + F32(30)).astype(F32)       # nerf.py:202
+    ph = np.asarray(phase_shifts, F32)
+    x = (inp * F32(2.0 / 51.0)).astype(F32)                                                   # UniformBoxWarp(51), :134-140,:193
+    for i in range(8):
+        x = film_layer(p[f"network.{i}.layer.weight"], p[f"network.{i}.layer.bias"], x,
+                       fr[:, i * H:(i + 1) * H], ph[:, i * H:(i + 1) * H])
+    sigma = (x @ p["final_layer.weight"].T + p["final_layer.bias"]).astype(F32)
+    if sigma_only:
+        return sigma
+    cin = np.concatenate([np.asarray(ray_directions, F32), x], -1)                            # :213
+    c = film_layer(p["color_layer_sine.layer.weight"], p["color_layer_sine.layer.bias"], cin, fr[:, -H:], ph[:, -H:])
+    pre = (c @ p["color_layer_linear.0.weight"].T + p["color_layer_linear.0.bias"]).astype(F32)
+    rgb = (F32(1) / (F32(1) + np.exp(-pre.astype(F64)))).astype(F32)
+    return np.concatenate([rgb, sigma], -1).astype(F32)

@@ -415,3 +415,54 @@ def test_training_step_decreases_loss(dev):
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < 0.6 * losses[0], losses
+
+
+# --------------------------------------------------------------------------- a7 (FiLM-SIREN)
+@pytest.fixture(scope="module")
+def siren(dev):
+    from nerf_siren_amd import SemanticNeRF
+    p = synth.siren_params(3)
+    m = SemanticNeRF()
+    r = m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    assert not r.missing_keys and not r.unexpected_keys
+    assert sum(q.numel() for q in m.parameters()) == 529156
+    return p, m.to(dev)
+
+
+def test_siren_forward_vs_reference(golden, dev, siren):
+    g = golden("g8_siren")
+    p, m = siren
+    with torch.no_grad():
+        out = N(m.forward_with_frequencies_phase_shifts(T(g["inp"], dev), T(g["freq"], dev), T(g["phase"], dev),
+                                                        T(g["dirs"], dev)))
+    assert out.shape == g["out"].shape
+    assert np.abs(out - g["out"]).max() < 1e-4               # north_star tolerance; typical 1e-6
+    assert np.abs(out - O.siren_forward(p, g["inp"], g["freq"], g["phase"], g["dirs"])).max() < 2e-5
+    with pytest.raises(AttributeError):                       # as the reference: mapping_network is undefined
+        m.forward(T(g["inp"], dev), None, T(g["dirs"], dev))
+
+
+def test_siren_render_rays(dev, siren, ops):
+    """SIREN field behind render_rays (coarse+fine, test_time and full) against the oracle pipeline."""
+    from nerf_siren_amd import Embedding, SirenField, render_rays
+    p, m = siren
+    freq, phase = synth.hash_normal((1, 2304), 301), synth.hash_normal((1, 2304), 302)
+    f = SirenField(m, T(freq, dev), T(phase, dev)).to(dev)
+    rays = synth.blender_rays(37, 33)
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    with torch.no_grad():
+        res = render_rays([f, f], emb, T(rays, dev), 64, False, 0, 0, 64, 1024 * 32, True, False)
+        rt = render_rays([f, f], emb, T(rays, dev), 64, False, 0, 0, 64, 1024 * 32, True, True)
+    # oracle pipeline with the SIREN field
+    z = O.sample_z(rays, 64)
+    pts = O.points(rays, z)
+    dirs = np.repeat(rays[:, None, 3:6], 64, 1)
+    o1 = O.siren_forward(p, pts.reshape(1, -1, 3), freq, phase, dirs.reshape(1, -1, 3)).reshape(37, 64, 4)
+    cc = O.composite(o1[..., 3], o1[..., :3], z, rays[:, 3:6], None, 0.0, True)
+    np.testing.assert_allclose(N(res["rgb_coarse"]), cc["rgb"], atol=2e-5)
+    np.testing.assert_allclose(N(res["opacity_coarse"]), cc["opacity"], atol=2e-5)
+    np.testing.assert_allclose(N(rt["opacity_coarse"]), cc["opacity"], atol=2e-5)
+    assert list(rt.keys()) == ["opacity_coarse", "rgb_fine", "depth_fine", "opacity_fine"]
+    assert torch.isfinite(res["rgb_fine"]).all() and (res["opacity_fine"] <= 1 + 1e-5).all()
+    with pytest.raises(NotImplementedError):
+        render_rays([f, f], emb, T(rays, dev), 64, False, 0, 0, 64, 1024 * 32, True, False)   # grad mode

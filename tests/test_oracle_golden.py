@@ -204,3 +204,17 @@ def test_render_rays_gradients(golden, case):
         assert w[0] < 5e-3 and w[1] < 5e-3, w
         for k in ("rgb_fine", "depth_fine", "opacity_fine"):
             assert np.abs(res[k] - g["out_" + k]).max() < 3e-6, k
+
+
+def test_siren_oracle_vs_reference(golden):
+    """FiLMLayer + SemanticNeRF.forward_with_frequencies_phase_shifts (nerf.py:142-216)."""
+    g = golden("g8_siren")
+    p = synth.siren_params(3)
+    assert sum(v.size for v in p.values()) == int(g["n_params"]) == 529156
+    out = O.siren_forward(p, g["inp"], g["freq"], g["phase"], g["dirs"])
+    assert np.abs(out - g["out"]).max() < 2e-6
+    film = O.film_layer(p["network.1.layer.weight"], p["network.1.layer.bias"], g["film_in"],
+                        g["freq"][:, :256], g["phase"][:, :256])
+    assert np.abs(film - g["film_out"]).max() < 5e-7
+    sig = O.siren_forward(p, g["inp"], g["freq"], g["phase"], g["dirs"], sigma_only=True)
+    assert np.array_equal(sig[..., 0], out[..., 3])

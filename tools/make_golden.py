@@ -295,7 +295,31 @@ def g_render(tag, rays, S, F, use_disp, perturb, noise_std, white_back, test_tim
          white_back=white_back, test_time=test_time, **out)
 
 
+# --------------------------------------------------------------------------- G8 (SIREN)
+def g_siren():
+    import models.nerf as MN
+    MN.np = np                      # nerf.py:131 uses np without importing it
+    m = MN.SemanticNeRF()
+    p = synth.siren_params(3)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+    Bz, Np = 3, 41
+    inp = ((synth.hash_uniform((Bz, Np, 3), 200) * 2 - 1) * 4).astype(np.float32)
+    dirs = synth.blender_rays(Bz * Np, 201)[:, 3:6].reshape(Bz, Np, 3)
+    freq = synth.hash_normal((Bz, 9 * 256), 202)
+    phase = synth.hash_normal((Bz, 9 * 256), 203)
+    with torch.no_grad():
+        out = m.forward_with_frequencies_phase_shifts(torch.from_numpy(inp), torch.from_numpy(freq),
+                                                      torch.from_numpy(phase), torch.from_numpy(dirs))
+        film = m.network[1](torch.from_numpy(synth.hash_normal((Bz, Np, 256), 204)),
+                            torch.from_numpy(freq[:, :256]), torch.from_numpy(phase[:, :256]))
+    save("g8_siren", inp=inp, dirs=dirs, freq=freq, phase=phase, out=out, film_in=synth.hash_normal((Bz, Np, 256), 204),
+         film_out=film, n_params=sum(q.numel() for q in m.parameters()))
+
+
 def main():
+    if "--only-siren" in sys.argv:
+        return g_siren()
+    g_siren()
     g_primitives()
     g_composite()
     g_sample_pdf()
