@@ -82,7 +82,7 @@ __device__ __forceinline__ void embed_xyz_blocks(float x, float y, float z, int 
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float s, c;
-            sincosf(__fmul_rn(xyz[d], (float)(1 << f)), &s, &c);
+            sincos_cw(__fmul_rn(xyz[d], (float)(1 << f)), s, c);
             v[3 + 6 * f + d] = s;
             v[3 + 6 * f + 3 + d] = c;
         }
@@ -107,7 +107,7 @@ __device__ __forceinline__ void embed_dir_block(float x, float y, float z, int h
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float s, c;
-            sincosf(__fmul_rn(xyz[d], (float)(1 << f)), &s, &c);
+            sincos_cw(__fmul_rn(xyz[d], (float)(1 << f)), s, c);
             v[3 + 6 * f + d] = s;
             v[3 + 6 * f + 3 + d] = c;
         }

@@ -14,6 +14,32 @@ constexpr int PF_DEFAULT = 6;  // weight-fragment groups (1 KiB each) in flight 
 
 __device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
+// sin / cos for |x| up to ~1e5 with ~1 ulp error and no branches: Cody-Waite reduction by pi/2 in two fma
+// steps (hi + lo split of pi/2), then the degree-7 sine / degree-8 cosine minimax polynomials on
+// [-pi/4, pi/4].  ~20 VALU instructions, against ~70 plus a divergent huge-argument path for the libm
+// call -- this matters where the sines ARE the VALU load: 2304 per point in the FiLM-SIREN field.
+__device__ __forceinline__ void sincos_cw(float x, float &s_out, float &c_out) {
+    const float j = rintf(x * 0.63661977236758134308f);              // x * 2/pi
+    float r = __builtin_fmaf(-j, 1.57079637050628662109375f, x);     // pi/2 hi (fp32)
+    r = __builtin_fmaf(-j, -4.37113900018624283e-8f, r);             // pi/2 lo
+    const float s2 = r * r;
+    float ps = __builtin_fmaf(s2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(s2, ps, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(r * s2, ps, r);
+    float pc = __builtin_fmaf(s2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(s2, pc, 4.166664568298827e-2f);
+    const float cs = __builtin_fmaf(s2 * s2, pc, __builtin_fmaf(-0.5f, s2, 1.0f));
+    const int q = (int)j;
+    const float sv = (q & 1) ? cs : sn, cv = (q & 1) ? sn : cs;
+    s_out = (q & 2) ? -sv : sv;
+    c_out = ((q + 1) & 2) ? -cv : cv;
+}
+__device__ __forceinline__ float sin_cw(float x) {
+    float s, c;
+    sincos_cw(x, s, c);
+    return s;
+}
+
 // out[jb] = epi(bias + W[jb-block rows] . [in0 ; in1])      (JB x (KB0+KB1) blocks)
 //   wp   : this layer's packed image + lane*4 (mlp_layout.h), streamed through a PF-deep register ring
 //   bias : natural order + 4*half, or nullptr for a zero start (backward)

@@ -104,7 +104,7 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float fr = __fadd_rn(__fmul_rn(f[t], 15.0f), 30.0f);          // nerf.py:202
-                c[t] = sinf(__fadd_rn(__fmul_rn(fr, c[t]), s[t]));                  // nerf.py:151
+                c[t] = sin_cw(__fadd_rn(__fmul_rn(fr, c[t]), s[t]));                  // nerf.py:151
             }
             return c;
         };
