@@ -170,3 +170,29 @@ def siren_params(seed: int = 0) -> dict:
         p[name + ".weight"] = w.astype(np.float32)
         p[name + ".bias"] = b.astype(np.float32)
     return p
+
+
+# ---------------------------------------------------------------------------
+# EG3D tri-plane renderer inputs
+# ---------------------------------------------------------------------------
+def osg_params(seed: int = 0) -> dict:
+    """OSGDecoder parameters (eg3d_training/triplane.py:144-153; FullyConnectedLayer init randn / lr_mul, bias 0
+    -- biases made non-zero here so that they are exercised)."""
+    return {"net.0.weight": hash_normal((64, 32), seed * 10 + 1), "net.0.bias": (hash_normal((64,), seed * 10 + 2) * 0.1).astype(np.float32),
+            "net.2.weight": hash_normal((4, 64), seed * 10 + 3), "net.2.bias": (hash_normal((4,), seed * 10 + 4) * 0.1).astype(np.float32)}
+
+
+def triplanes(seed: int = 0, res: int = 64, channels: int = 32, n: int = 1) -> np.ndarray:
+    """(n, 3, channels, res, res) feature planes, N(0,1)."""
+    return hash_normal((n, 3, channels, res, res), 7000 + seed)
+
+
+EG3D_OPTIONS = dict(depth_resolution=64, depth_resolution_importance=64, ray_start=0.1, ray_end=10.0, box_warp=15.0,
+                    white_back=False, clamp_mode="softplus", disparity_space_sampling=False)   # eg3d_renderer.py:30-36
+
+
+def eg3d_rays(n_rays: int, seed: int = 0, radius: float = 2.7):
+    """Rays from cameras on a sphere of avg_camera_radius 2.7 looking at the origin (eg3d_renderer.py:30)."""
+    r = blender_rays(n_rays, seed)
+    o = (r[:, 0:3] * np.float32(radius / LEGO_RADIUS)).astype(np.float32)
+    return o, r[:, 3:6].copy()

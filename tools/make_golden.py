@@ -316,9 +316,104 @@ def g_siren():
          film_out=film, n_params=sum(q.numel() for q in m.parameters()))
 
 
+# --------------------------------------------------------------------------- G9..G14 (EG3D)
+def g_eg3d():
+    from volumetric_rendering.renderer import ImportanceRenderer, sample_from_planes, generate_planes
+    from volumetric_rendering.ray_marcher import MipRayMarcher2
+    from volumetric_rendering.ray_sampler import RaySampler
+    from volumetric_rendering import math_utils
+    from eg3d_training.triplane import OSGDecoder
+
+    dec = OSGDecoder(32, {"decoder_lr_mul": 1.0, "decoder_output_dim": 3})
+    dp = synth.osg_params(4)
+    dec.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in dp.items()})
+    opts = dict(synth.EG3D_OPTIONS)
+    ren = ImportanceRenderer()
+
+    # G9 run_model on chosen points: inside, outside the box (zero padding), texel centres and borders
+    planes = torch.from_numpy(synth.triplanes(5, res=16))
+    P = 300
+    c = ((synth.hash_uniform((1, P, 3), 400) * 2 - 1) * 9.0).astype(np.float32)       # box half-size 7.5 -> some outside
+    c[0, 0] = 0
+    c[0, 1] = [7.5, -7.5, 7.5]
+    c[0, 2] = [7.5 * (1 - 1 / 16), 7.5 * (-1 + 1 / 16), 0.0]                          # texel centres
+    c[0, 3] = [7.5 * (1 + 1 / 16), 0, 0]                                              # half a texel outside
+    c[0, 4] = [1e3, -1e3, 5e2]
+    with torch.no_grad():
+        feats = sample_from_planes(generate_planes(), planes, torch.from_numpy(c), padding_mode="zeros", box_warp=15.0)
+        out = ren.run_model(planes, dec, torch.from_numpy(c), None, opts)
+    save("g9_eg3d_run_model", coords=c, feats=feats, rgb=out["rgb"], sigma=out["sigma"])
+
+    # G10 marcher
+    N, M, S = 1, 37, 64
+    col = synth.hash_uniform((N, M, S, 3), 410)
+    den = (synth.hash_normal((N, M, S, 1), 411) * 3).astype(np.float32)
+    dep = np.sort(synth.hash_uniform((N, M, S, 1), 412) * 9.9 + 0.1, 2).astype(np.float32)
+    den[0, 0] = -60                                   # softplus -> ~0: sum w == 0 -> nan -> inf -> clamp(max)
+    den[0, 1] = 50
+    march = MipRayMarcher2()
+    for wb in (False, True):
+        o2 = dict(opts, white_back=wb)
+        with torch.no_grad():
+            r, d, w = march.run_forward(torch.from_numpy(col), torch.from_numpy(den), torch.from_numpy(dep), o2)
+        save(f"g10_eg3d_march_wb{int(wb)}", colors=col, densities=den, depths=dep, rgb=r, depth=d, weights=w)
+
+    # G11 sample_importance with the captured rand
+    u = synth.hash_uniform((N * M, 64), 420)
+    w_in = (synth.hash_uniform((N, M, S - 1, 1), 421) ** 5).astype(np.float32)
+    w_in[0, 2] = 0
+    _rand = torch.rand
+    torch.rand = lambda *a, **k: torch.from_numpy(u.copy())
+    try:
+        with torch.no_grad():
+            zf = ren.sample_importance(torch.from_numpy(dep), torch.from_numpy(w_in), 64)
+    finally:
+        torch.rand = _rand
+    save("g11_eg3d_importance", depths=dep, weights=w_in, u=u, z_fine=zf)
+
+    # G12 full forward
+    planes = torch.from_numpy(synth.triplanes(6, res=64))
+    M = 50
+    o, d = synth.eg3d_rays(M, 61)
+    rs = synth.hash_uniform((1, M, 64, 1), 430)
+    u2 = synth.hash_uniform((M, 64), 431)
+    _rand, _rl = torch.rand, torch.rand_like
+    torch.rand = lambda *a, **k: torch.from_numpy(u2.copy())
+    torch.rand_like = lambda t, **k: torch.from_numpy(rs.copy())
+    try:
+        with torch.no_grad():
+            res = ren(planes, dec, torch.from_numpy(o[None]), torch.from_numpy(d[None]), opts)
+    finally:
+        torch.rand, torch.rand_like = _rand, _rl
+    save("g12_eg3d_forward", ray_o=o, ray_d=d, rand_strat=rs, u=u2, rgb_c=res[0], depth_c=res[1], op_c=res[2],
+         rgb_f=res[3], depth_f=res[4], op_f=res[5])
+
+    # G13 RaySampler
+    c2w = np.stack([np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)])
+    c2w[1, :3, :] = synth._look_at_c2w(0.4, 1.1, 2.7)
+    intr = np.array([[[1.0, 0.0, 0.5], [0, 1.0, 0.5], [0, 0, 1]], [[4.26, 0.02, 0.48], [0, 4.1, 0.52], [0, 0, 1]]], np.float32)
+    for res_ in (2, 8):
+        with torch.no_grad():
+            ro, rd = RaySampler()(torch.from_numpy(c2w), torch.from_numpy(intr), res_)
+        save(f"g13_eg3d_raysampler_{res_}", cam2world=c2w, intrinsics=intr, origins=ro, dirs=rd)
+
+    # G14 get_ray_limits_box
+    ro = ((synth.hash_uniform((1, 64, 3), 440) * 2 - 1) * 3).astype(np.float32)
+    rd = synth.blender_rays(64, 441)[:, 3:6][None].copy()
+    rd[0, 0] = [1, 0, 0]
+    ro[0, 0] = [0, 5, 0]          # parallel to a slab, outside -> miss
+    rd[0, 1] = [0, 0, 1]
+    ro[0, 1] = [0.1, 0.1, -5]     # axis aligned hit (1/0 = inf in two axes)
+    tmin, tmax = math_utils.get_ray_limits_box(torch.from_numpy(ro), torch.from_numpy(rd), 2.0)
+    save("g14_eg3d_box", ray_o=ro, ray_d=rd, tmin=tmin, tmax=tmax)
+
+
 def main():
     if "--only-siren" in sys.argv:
         return g_siren()
+    if "--only-eg3d" in sys.argv:
+        return g_eg3d()
+    g_eg3d()
     g_siren()
     g_primitives()
     g_composite()
