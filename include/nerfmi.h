@@ -153,6 +153,56 @@ int nerfmi_importance_resample(const float *z_coarse, const float *weights_coars
                                int n_samples, int n_importance, float *z_new_out, float *z_fine_out,
                                nerfmi_stream_t stream);
 
+/* ==== EG3D tri-plane importance renderer (forward) ========================================================
+ * volumetric_rendering/renderer.py, ray_marcher.py, ray_sampler.py, math_utils.py; eg3d_training/triplane.py.
+ * Planes are consumed channels-last: planes_hwc (n*3, H, W, 32), produced once per plane update from the
+ * reference's (n,3,32,H,W) layout (triplane.py:65).  R below = number of rays of the call (N*M). */
+int nerfmi_eg3d_pack_planes(const float *planes_nchw, int n_planes /* = n*3 */, int channels, int h, int w,
+                            float *planes_hwc, nerfmi_stream_t stream);
+/* OSGDecoder (triplane.py:144-167) = FullyConnectedLayer(32,64) -> Softplus -> FullyConnectedLayer(64,4)
+ * (networks_stylegan2.py:96-127: w*lr_mul/sqrt(in), b*lr_mul).  packed: nerfmi_eg3d_decoder_floats() floats. */
+size_t nerfmi_eg3d_decoder_floats(void);
+int nerfmi_eg3d_pack_decoder(const float *w0, const float *b0, const float *w1, const float *b1, float lr_multiplier,
+                             float *packed, nerfmi_stream_t stream);
+/* sample_from_planes (renderer.py:55-65): coords (n, n_points, 3) -> feats_out (n, 3, n_points, 32). */
+int nerfmi_eg3d_sample_planes(const float *planes_hwc, int n, int h, int w, const float *coords, int64_t n_points,
+                              float box_warp, float *feats_out, nerfmi_stream_t stream);
+/* run_model (renderer.py:144-151) fused with the decoder: rgb_out (n, n_points, 3), sigma_out (n, n_points). */
+int nerfmi_eg3d_run_model(const float *planes_hwc, int n, int h, int w, const float *decoder_packed,
+                          const float *coords, int64_t n_points, float box_warp, float *rgb_out, float *sigma_out,
+                          nerfmi_stream_t stream);
+/* the same with coords = ray_origins + depths * ray_directions (renderer.py:105, :125);
+ * ray_* (n, M, 3), depths (n, M, n_samples), outputs (n, M*n_samples, .). */
+int nerfmi_eg3d_run_model_rays(const float *planes_hwc, int n, int h, int w, const float *decoder_packed,
+                               const float *ray_origins, const float *ray_directions, const float *depths,
+                               int64_t n_rays_per_batch, int n_samples, float box_warp, float *rgb_out,
+                               float *sigma_out, nerfmi_stream_t stream);
+/* sample_stratified (renderer.py:172-195); rand = the rand_like draw (R, n_samples).  ray_start_t/ray_end_t (R)
+ * select the per-ray ('auto') branch, else the scalar ray_start/ray_end (+ optional disparity sampling). */
+int nerfmi_eg3d_sample_stratified(const float *ray_start_t, const float *ray_end_t, float ray_start, float ray_end,
+                                  const float *rand, int64_t n_rays, int n_samples, int disparity, float *depths_out,
+                                  nerfmi_stream_t stream);
+/* torch.min / torch.max over all depths of the call (ray_marcher.py:50) -> minmax_out[2] on the device. */
+int nerfmi_eg3d_minmax(const float *x, int64_t n, float *minmax_out, nerfmi_stream_t stream);
+/* MipRayMarcher2.run_forward (ray_marcher.py:25-57): colors (R,S,3), densities (R,S), depths (R,S) ->
+ * rgb_out (R,3), depth_out (R), weights_out (R,S-1) [optional], weight_sum_out (R) [optional]. */
+int nerfmi_eg3d_march(const float *colors, const float *densities, const float *depths, const float *minmax,
+                      int64_t n_rays, int n_samples, int white_back, float *rgb_out, float *depth_out,
+                      float *weights_out, float *weight_sum_out, nerfmi_stream_t stream);
+/* sample_importance (renderer.py:197-256): depths (R,S), weights (R,S-1), u (R,F) = the torch.rand draw -> z_out (R,F). */
+int nerfmi_eg3d_sample_importance(const float *depths, const float *weights, const float *u, int64_t n_rays,
+                                  int n_samples, int n_importance, float *z_out, nerfmi_stream_t stream);
+/* unify_samples (renderer.py:160-170): sort by depth and gather colours (.,3) and densities. */
+int nerfmi_eg3d_unify(const float *d1, const float *c1, const float *s1, const float *d2, const float *c2,
+                      const float *s2, int64_t n_rays, int n1, int n2, float *d_out, float *c_out, float *s_out,
+                      nerfmi_stream_t stream);
+/* RaySampler.forward (ray_sampler.py:24-63): cam2world (n,4,4), intrinsics (n,3,3) -> origins/dirs (n, res*res, 3). */
+int nerfmi_eg3d_ray_sampler(const float *cam2world, const float *intrinsics, int n, int resolution, float *origins_out,
+                            float *dirs_out, nerfmi_stream_t stream);
+/* get_ray_limits_box (math_utils.py:46-98): (n,3),(n,3) -> tmin (n), tmax (n); misses = (-1,-2). */
+int nerfmi_eg3d_ray_limits_box(const float *rays_o, const float *rays_d, int64_t n, float box_side_length,
+                               float *tmin_out, float *tmax_out, nerfmi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,12 @@ def __getattr__(name):
     if name in ("Embedding", "NeRF", "SemanticNeRF", "FiLMLayer", "SirenField"):
         from . import nerf
         return getattr(nerf, name)
+    if name in ("OSGDecoder", "FullyConnectedLayer"):
+        from . import eg3d
+        return getattr(eg3d, name)
+    if name in ("ImportanceRenderer", "MipRayMarcher2", "RaySampler"):
+        from . import volumetric_rendering
+        return getattr(volumetric_rendering, name)
     if name == "searchsorted":
         from . import ops
         return ops.searchsorted

@@ -31,6 +31,19 @@ SIGNATURES = {
     "nerfmi_siren_pack": (_i, [C.POINTER(C.c_void_p), _f, _f]),
     "nerfmi_siren_forward_points": (_i, [_f, _f, _f, _f, _f, _i64, _i64, _i, _f, _f]),
     "nerfmi_siren_forward_rays": (_i, [_f, _f, _f, _f, _f, _i, _i, _i64, _i, _f, _f]),
+    "nerfmi_eg3d_pack_planes": (_i, [_f, _i, _i, _i, _i, _f, _f]),
+    "nerfmi_eg3d_decoder_floats": (C.c_size_t, []),
+    "nerfmi_eg3d_pack_decoder": (_i, [_f, _f, _f, _f, _fl, _f, _f]),
+    "nerfmi_eg3d_sample_planes": (_i, [_f, _i, _i, _i, _f, _i64, _fl, _f, _f]),
+    "nerfmi_eg3d_run_model": (_i, [_f, _i, _i, _i, _f, _f, _i64, _fl, _f, _f, _f]),
+    "nerfmi_eg3d_run_model_rays": (_i, [_f, _i, _i, _i, _f, _f, _f, _f, _i64, _i, _fl, _f, _f, _f]),
+    "nerfmi_eg3d_sample_stratified": (_i, [_f, _f, _fl, _fl, _f, _i64, _i, _i, _f, _f]),
+    "nerfmi_eg3d_minmax": (_i, [_f, _i64, _f, _f]),
+    "nerfmi_eg3d_march": (_i, [_f, _f, _f, _f, _i64, _i, _i, _f, _f, _f, _f, _f]),
+    "nerfmi_eg3d_sample_importance": (_i, [_f, _f, _f, _i64, _i, _i, _f, _f]),
+    "nerfmi_eg3d_unify": (_i, [_f, _f, _f, _f, _f, _f, _i64, _i, _i, _f, _f, _f, _f]),
+    "nerfmi_eg3d_ray_sampler": (_i, [_f, _f, _i, _i, _f, _f, _f]),
+    "nerfmi_eg3d_ray_limits_box": (_i, [_f, _f, _i64, _fl, _f, _f, _f]),
     "nerfmi_composite": (_i, [_f, _i, _f, _f, _f, _fl, _i, _i, _i, _f, _f, _f, _f, _f]),
     "nerfmi_composite_backward": (_i, [_f, _f, _f, _f, _fl, _i, _i, _i, _f, _f, _f, _f, _f]),
     "nerfmi_sample_pdf": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _f, _f]),

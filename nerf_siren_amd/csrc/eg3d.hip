@@ -1,0 +1,604 @@
+// EG3D tri-plane importance renderer for gfx950 (MI355X) -- forward path of
+//   volumetric_rendering/renderer.py:23-256   (ImportanceRenderer, sample_from_planes, ...)
+//   volumetric_rendering/ray_marcher.py:25-57 (MipRayMarcher2)
+//   volumetric_rendering/ray_sampler.py:24-63 (RaySampler)
+//   volumetric_rendering/math_utils.py:46-118 (get_ray_limits_box, linspace)
+//   eg3d_training/triplane.py:144-167         (OSGDecoder)
+//
+// The reference keeps the planes NCHW, so the 32 channels of one texel are H*W*4
+// bytes apart and a bilinear tap touches 32 cache lines.  Here the planes are
+// re-packed once to channels-last (N,3,H,W,32): a texel is ONE 128-byte line and
+// a sample needs 12 line reads (3 planes x 4 taps).  The path is gather bound
+// (1.5 KB of texels vs 4.6 kFLOP per sample), so the decoder (32->64->4, weights
+// held in SGPRs via uniform loads) is fused behind the gather, one sample per
+// lane, and the features never exist in memory.  Per-ray kernels (marcher,
+// importance resampling, unify) use one wavefront per ray like rays.hip.
+#include "common.h"
+
+namespace nerfmi {
+
+constexpr int EC = 32;                 // feature channels per plane (triplane.py:65)
+constexpr int DEC_H = 64;              // OSGDecoder hidden width (triplane.py:147)
+constexpr int DEC_FLOATS = DEC_H * EC + DEC_H + 4 * DEC_H + 4;
+
+// ---------------------------------------------------------------------------
+// re-packing
+// ---------------------------------------------------------------------------
+__global__ void pack_planes_kernel(const float *__restrict__ src, int64_t n_img, int C, int H, int W,
+                                   float *__restrict__ dst) {
+    const int64_t total = n_img * C * H * W;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);                 // dst index order: (img, y, x, c)
+        const int64_t pix = idx / C;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int64_t img = pix / ((int64_t)W * H);
+        dst[idx] = src[((img * C + c) * H + y) * W + x];
+    }
+}
+
+// FullyConnectedLayer (networks_stylegan2.py:96-127): w = weight * (lr_mul/sqrt(in)), b = bias * lr_mul
+__global__ void pack_decoder_kernel(const float *__restrict__ w0, const float *__restrict__ b0,
+                                    const float *__restrict__ w1, const float *__restrict__ b1, float lr_mul,
+                                    float *__restrict__ out) {
+    const float g0 = (float)((double)lr_mul / sqrt((double)EC)), g1 = (float)((double)lr_mul / sqrt((double)DEC_H));
+    for (int i = threadIdx.x; i < DEC_FLOATS; i += blockDim.x) {
+        float v;
+        if (i < DEC_H * EC) v = __fmul_rn(w0[i], g0);
+        else if (i < DEC_H * EC + DEC_H) v = (lr_mul != 1.f) ? __fmul_rn(b0[i - DEC_H * EC], lr_mul) : b0[i - DEC_H * EC];
+        else if (i < DEC_H * EC + DEC_H + 4 * DEC_H) v = __fmul_rn(w1[i - DEC_H * EC - DEC_H], g1);
+        else v = (lr_mul != 1.f) ? __fmul_rn(b1[i - DEC_H * EC - DEC_H - 4 * DEC_H], lr_mul) : b1[i - DEC_H * EC - DEC_H - 4 * DEC_H];
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a9: tri-plane bilinear sampling (+ fused a10 decoder)
+// ---------------------------------------------------------------------------
+// F.grid_sample(bilinear, padding zeros, align_corners=False) of one channels-last plane at (gx,gy):
+// acc[c] = nw*v_nw + ne*v_ne + sw*v_sw + se*v_se (ATen order), out-of-range taps contribute 0.
+__device__ __forceinline__ void bilinear_plane(const float *__restrict__ plane, int H, int W, float gx, float gy,
+                                               float (&f)[EC]) {
+    const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)W), 1.f), 2.f);
+    const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)H), 1.f), 2.f);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+    const float wx1 = __fsub_rn(ix, x0f), wx0 = __fsub_rn(x1f, ix);
+    const float wy1 = __fsub_rn(iy, y0f), wy0 = __fsub_rn(y1f, iy);
+    const float wgt[4] = {__fmul_rn(wx0, wy0), __fmul_rn(wx1, wy0), __fmul_rn(wx0, wy1), __fmul_rn(wx1, wy1)};
+    const float xs[4] = {x0f, x1f, x0f, x1f}, ys[4] = {y0f, y0f, y1f, y1f};
+#pragma unroll
+    for (int c = 0; c < EC; ++c) f[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        // NaN / huge coordinates fail these comparisons and are treated as out of range
+        const bool ok = xs[t] >= 0.f && xs[t] < (float)W && ys[t] >= 0.f && ys[t] < (float)H;
+        if (ok) {
+            const float4 *tex = reinterpret_cast<const float4 *>(plane + ((int64_t)(int)ys[t] * W + (int)xs[t]) * EC);
+#pragma unroll
+            for (int v = 0; v < EC / 4; ++v) {
+                const float4 q = tex[v];
+                f[4 * v + 0] = __fadd_rn(f[4 * v + 0], __fmul_rn(q.x, wgt[t]));
+                f[4 * v + 1] = __fadd_rn(f[4 * v + 1], __fmul_rn(q.y, wgt[t]));
+                f[4 * v + 2] = __fadd_rn(f[4 * v + 2], __fmul_rn(q.z, wgt[t]));
+                f[4 * v + 3] = __fadd_rn(f[4 * v + 3], __fmul_rn(q.w, wgt[t]));
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// MODE 0: features out (N,3,P,C)   [sample_from_planes, renderer.py:55-65]
+// MODE 1: fused decoder -> rgb (N,P,3), sigma (N,P)   [run_model, renderer.py:144-151 + triplane.py:155-167]
+// coords: explicit (N,P,3), or built as o + depth*d from rays (N,M,3) and depths (N,M,S) with P = M*S.
+template <int MODE, bool FROM_RAYS>
+__global__ void __launch_bounds__(256)
+triplane_kernel(const float *__restrict__ planes, int N, int H, int W, const float *__restrict__ coords,
+                const float *__restrict__ ray_o, const float *__restrict__ ray_d, const float *__restrict__ depths,
+                int S, int64_t P, float coord_scale, const float *__restrict__ dec, float *__restrict__ feats,
+                float *__restrict__ rgb, float *__restrict__ sigma) {
+    const int64_t total = (int64_t)N * P;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = idx / P, p = idx % P;
+        float c[3];
+        if (FROM_RAYS) {
+            const int64_t ray = n * (P / S) + p / S;
+            const float dz = depths[idx];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c[k] = __fadd_rn(ray_o[ray * 3 + k], __fmul_rn(dz, ray_d[ray * 3 + k]));   // renderer.py:105
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c[k] = coords[idx * 3 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[k] = __fmul_rn(coord_scale, c[k]);          // (2/box_warp) * coordinates, :61
+        // project_onto_planes (:39-53): coordinates @ inv(axes) -> (x,y), (x,z), (z,x)
+        const int sa[3] = {0, 0, 2}, sb[3] = {1, 2, 0};
+        float f[EC], m[EC];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            bilinear_plane(planes + ((n * 3 + pl) * (int64_t)H * W) * EC, H, W, c[sa[pl]], c[sb[pl]], f);
+            if (MODE == 0) {
+                float4 *o = reinterpret_cast<float4 *>(feats + ((n * 3 + pl) * P + p) * EC);
+#pragma unroll
+                for (int v = 0; v < EC / 4; ++v) o[v] = make_float4(f[4 * v], f[4 * v + 1], f[4 * v + 2], f[4 * v + 3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < EC; ++k) m[k] = (pl == 0) ? f[k] : __fadd_rn(m[k], f[k]);
+            }
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < EC; ++k) m[k] = __fdiv_rn(m[k], 3.f);             // sampled_features.mean(1), triplane.py:157
+            const float *w0 = dec, *b0 = dec + DEC_H * EC, *w1 = b0 + DEC_H, *b1 = w1 + 4 * DEC_H;
+            float o4[4] = {b1[0], b1[1], b1[2], b1[3]};
+            for (int j = 0; j < DEC_H; ++j) {                                     // uniform addresses -> scalar loads
+                float h = b0[j];
+#pragma unroll
+                for (int k = 0; k < EC; ++k) h = __builtin_fmaf(w0[j * EC + k], m[k], h);
+                h = softplus_f(h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o4[k] = __builtin_fmaf(w1[k * DEC_H + j], h, o4[k]);
+            }
+            sigma[idx] = o4[0];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float sg = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-o4[1 + k])));
+                rgb[idx * 3 + k] = __fsub_rn(__fmul_rn(sg, 1.002f), 0.001f);      // triplane.py:165
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a12: stratified depths (renderer.py:172-195)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float linspace_at(float start, float end, int i, int n) {
+    if (n <= 1) return start;
+    const float step = __fdiv_rn(__fsub_rn(end, start), (float)(n - 1));
+    return (i < n / 2) ? __builtin_fmaf(step, (float)i, start) : __builtin_fmaf(-step, (float)(n - 1 - i), end);
+}
+
+// per_ray: start/end are (R) tensors (the 'auto' branch, math_utils.linspace); else scalars start_s/end_s
+__global__ void eg3d_stratified_kernel(const float *__restrict__ start_t, const float *__restrict__ end_t, float start_s,
+                                       float end_s, float delta_s, const float *__restrict__ rand, int64_t R, int S,
+                                       int disparity, float *__restrict__ out) {
+    const int64_t total = R * S;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % S);
+        const int64_t r = idx / S;
+        float d;
+        if (start_t) {
+            const float a = start_t[r], b = end_t[r], span = __fsub_rn(b, a);
+            const float step = __fdiv_rn((float)i, (float)(S - 1));
+            d = __fadd_rn(a, __fmul_rn(step, span));
+            d = __fadd_rn(d, __fmul_rn(rand[idx], __fdiv_rn(span, (float)(S - 1))));
+        } else if (disparity) {
+            float t = linspace01(i, S);
+            t = __fadd_rn(t, __fmul_rn(rand[idx], delta_s));
+            const float a = __fmul_rn(start_s, __fsub_rn(1.f, t)), b = __fmul_rn(end_s, t);   // start_s/end_s = 1/ray_start, 1/ray_end
+            d = __fdiv_rn(1.f, __fadd_rn(a, b));
+        } else {
+            d = __fadd_rn(linspace_at(start_s, end_s, i, S), __fmul_rn(rand[idx], delta_s));
+        }
+        out[idx] = d;
+    }
+}
+
+// global min / max of the depths of one call (ray_marcher.py:50): one workgroup, deterministic
+__global__ void __launch_bounds__(1024) minmax_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+    __shared__ float smin[16], smax[16];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = x[i];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, m, WAVE));
+        hi = fmaxf(hi, __shfl_xor(hi, m, WAVE));
+    }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fminf(lo, smin[w]); hi = fmaxf(hi, smax[w]); }
+        out[0] = lo;
+        out[1] = hi;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a11: MipRayMarcher2.run_forward (ray_marcher.py:25-57): one wave per ray,
+// lane l owns intervals [l*SPL, l*SPL+SPL)
+// ---------------------------------------------------------------------------
+template <int SPL>
+__global__ void __launch_bounds__(64)
+mip_march_kernel(const float *__restrict__ colors, const float *__restrict__ dens, const float *__restrict__ depths,
+                 const float *__restrict__ minmax, int64_t R, int S, int white_back, float *__restrict__ rgb_out,
+                 float *__restrict__ depth_out, float *__restrict__ w_out, float *__restrict__ wsum_out) {
+    const int lane = threadIdx.x;
+    const int NI = S - 1;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const float *cr = colors + r * S * 3, *dr = dens + r * S, *zr = depths + r * S;
+        float alpha[SPL], cm[SPL][3], zm[SPL];
+        double pl[SPL], lp = 1.0;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const int i = lane * SPL + j;
+            const bool ok = i < NI;
+            const int ic = ok ? i : (NI > 0 ? NI - 1 : 0);
+            const float z0 = zr[ic], z1 = zr[ic + 1];
+            const float delta = __fsub_rn(z1, z0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) cm[j][k] = __fdiv_rn(__fadd_rn(cr[ic * 3 + k], cr[(ic + 1) * 3 + k]), 2.f);
+            float dm = __fdiv_rn(__fadd_rn(dr[ic], dr[ic + 1]), 2.f);
+            zm[j] = __fdiv_rn(__fadd_rn(z0, z1), 2.f);
+            dm = __fsub_rn(dm, 1.f);
+            // softplus / exp in fp64 rounded once (the oracle's specification; torch's are within 1 ulp)
+            const float sp = dm > 20.f ? dm : (float)log1p(exp((double)dm));
+            const float e = (float)exp(-(double)__fmul_rn(sp, delta));
+            alpha[j] = ok ? __fsub_rn(1.f, e) : 0.f;
+            const float a = ok ? __fadd_rn(__fsub_rn(1.f, alpha[j]), 1e-10f) : 1.f;
+            pl[j] = lp;
+            lp *= (double)a;
+        }
+        const double incl = wave_incl_prod_d(lp, lane);
+        double excl = shfl_up_d(incl, 1);
+        if (lane == 0) excl = 1.0;
+        double sw = 0, s0 = 0, s1 = 0, s2 = 0, sz = 0;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const int i = lane * SPL + j;
+            if (i < NI) {
+                const float w = __fmul_rn(alpha[j], (float)(excl * pl[j]));
+                if (w_out) w_out[r * NI + i] = w;
+                sw += (double)w;
+                s0 += (double)__fmul_rn(w, cm[j][0]);
+                s1 += (double)__fmul_rn(w, cm[j][1]);
+                s2 += (double)__fmul_rn(w, cm[j][2]);
+                sz += (double)__fmul_rn(w, zm[j]);
+            }
+        }
+        sw = wave_sum_d(sw); s0 = wave_sum_d(s0); s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); sz = wave_sum_d(sz);
+        if (lane == 0) {
+            const float wt = (float)sw;
+            float c0 = (float)s0, c1 = (float)s1, c2 = (float)s2;
+            float d = __fdiv_rn((float)sz, wt);                       // :47
+            if (isnan(d)) d = INFINITY;                               // nan_to_num(inf), :49
+            d = fminf(fmaxf(d, minmax[0]), minmax[1]);                // clamp(min(depths), max(depths)), :50
+            if (white_back) {
+                c0 = __fsub_rn(__fadd_rn(c0, 1.f), wt);
+                c1 = __fsub_rn(__fadd_rn(c1, 1.f), wt);
+                c2 = __fsub_rn(__fadd_rn(c2, 1.f), wt);
+            }
+            rgb_out[r * 3 + 0] = c0; rgb_out[r * 3 + 1] = c1; rgb_out[r * 3 + 2] = c2;
+            depth_out[r] = d;
+            if (wsum_out) wsum_out[r] = wt;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a12: sample_importance (renderer.py:197-256): max_pool1d(2,1,1) -> avg_pool1d(2,1) -> +0.01 ->
+// sample_pdf(z_mid, w[:,1:-1], F) with the rand draw u.  LDS: wsm[S+1] | cdf[S-2] | bins[S-1]
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+eg3d_importance_kernel(const float *__restrict__ depths, const float *__restrict__ weights, const float *__restrict__ u,
+                       int64_t R, int S, int F, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const int NI = S - 1;            // weights per ray
+    const int nw = S - 3;            // pdf weights = smoothed[1:-1]
+    float *sm = lds;                 // smoothed weights, NI entries
+    float *cdf = lds + S + 1;        // nw + 1 entries
+    float *bins = cdf + (nw + 1) + 1;   // NI entries (z_mid)
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        __syncthreads();
+        const float *wr = weights + r * NI, *zr = depths + r * S;
+        for (int i = lane; i < NI; i += WAVE) {
+            // mx[i] = max(w[i-1], w[i]) (pad -inf), i in [0,S); sm[i] = (mx[i] + mx[i+1]) / 2 + 0.01
+            const float wm1 = i > 0 ? wr[i - 1] : -INFINITY, w0 = wr[i], wp1 = i + 1 < NI ? wr[i + 1] : -INFINITY;
+            const float a = fmaxf(wm1, w0), b = fmaxf(w0, wp1);
+            sm[i] = __fadd_rn(__fdiv_rn(__fadd_rn(a, b), 2.f), 0.01f);
+            bins[i] = __fmul_rn(0.5f, __fadd_rn(zr[i], zr[i + 1]));
+        }
+        __syncthreads();
+        // cdf over sm[1 .. NI-2]  (same arithmetic as rays.hip build_cdf_lds)
+        double ls = 0;
+        for (int k = lane; k < nw; k += WAVE) {
+            const float w = __fadd_rn(sm[1 + k], 1e-5f);
+            cdf[1 + k] = w;
+            ls += (double)w;
+        }
+        const float tot = (float)wave_sum_d(ls);
+        __syncthreads();
+        for (int k = lane; k < nw; k += WAVE) cdf[1 + k] = __fdiv_rn(cdf[1 + k], tot);
+        __syncthreads();
+        const int chunk = (nw + WAVE - 1) / WAVE;
+        const int k0 = lane * chunk, k1 = min(k0 + chunk, nw);
+        double loc = 0;
+        for (int k = k0; k < k1; ++k) loc += (double)cdf[1 + k];
+        const double incl = wave_incl_sum_d(loc, lane);
+        double run = incl - loc;
+        __syncthreads();
+        for (int k = k0; k < k1; ++k) { run += (double)cdf[1 + k]; cdf[1 + k] = (float)run; }
+        if (lane == 0) cdf[0] = 0.f;
+        __syncthreads();
+        for (int f = lane; f < F; f += WAVE) {
+            const float uu = u[r * F + f];
+            int lo = 0, hi = nw + 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= uu) lo = mid + 1; else hi = mid; }
+            const int below = max(lo - 1, 0), above = min(lo, nw);
+            const float cb = cdf[below], ca = cdf[above], bb = bins[below], ba = bins[above];
+            float denom = __fsub_rn(ca, cb);
+            if (denom < 1e-5f) denom = 1.f;
+            out[r * F + f] = __fadd_rn(bb, __fmul_rn(__fdiv_rn(__fsub_rn(uu, cb), denom), __fsub_rn(ba, bb)));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// unify_samples (renderer.py:160-170): sort the S+F depths of a ray and gather colours/densities
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+eg3d_unify_kernel(const float *__restrict__ d1, const float *__restrict__ c1, const float *__restrict__ s1,
+                  const float *__restrict__ d2, const float *__restrict__ c2, const float *__restrict__ s2, int64_t R,
+                  int S, int F, int npad, float *__restrict__ d_out, float *__restrict__ c_out,
+                  float *__restrict__ s_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *key = lds;
+    int *idx = reinterpret_cast<int *>(lds + npad);
+    const int lane = threadIdx.x, n = S + F;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        __syncthreads();
+        for (int k = lane; k < npad; k += WAVE) {
+            key[k] = k < S ? d1[r * S + k] : (k < n ? d2[r * F + (k - S)] : INFINITY);
+            idx[k] = k;
+        }
+        __syncthreads();
+        for (int kk = 2; kk <= npad; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < npad / 2; t += WAVE) {
+                    const int i = ((t / j) * 2 * j) + (t % j), p = i + j;
+                    const bool up = ((i & kk) == 0);
+                    const float a = key[i], b = key[p];
+                    const int ia = idx[i], ib = idx[p];
+                    // ties broken by original position -> a stable order
+                    const bool gt = (a > b) || (a == b && ia > ib);
+                    if (gt == up) { key[i] = b; key[p] = a; idx[i] = ib; idx[p] = ia; }
+                }
+                __syncthreads();
+            }
+        for (int k = lane; k < n; k += WAVE) {
+            const int src = idx[k];
+            d_out[r * n + k] = key[k];
+            const float *cs = src < S ? c1 + (r * S + src) * 3 : c2 + (r * F + (src - S)) * 3;
+            c_out[(r * n + k) * 3 + 0] = cs[0];
+            c_out[(r * n + k) * 3 + 1] = cs[1];
+            c_out[(r * n + k) * 3 + 2] = cs[2];
+            s_out[r * n + k] = src < S ? s1[r * S + src] : s2[r * F + (src - S)];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a13 RaySampler.forward (ray_sampler.py:24-63), a14 get_ray_limits_box (math_utils.py:46-98)
+// ---------------------------------------------------------------------------
+__global__ void ray_sampler_kernel(const float *__restrict__ c2w, const float *__restrict__ intr, int N, int res,
+                                   float *__restrict__ o_out, float *__restrict__ d_out) {
+    const int64_t M = (int64_t)res * res, total = N * M;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = idx / M, m = idx % M;
+        const float *K = intr + n * 9, *C = c2w + n * 16;
+        const float fx = K[0], fy = K[4], cx = K[2], cy = K[5], sk = K[1];
+        const float inv = __fdiv_rn(1.f, (float)res), half = __fdiv_rn(0.5f, (float)res);
+        const float xc = __fadd_rn(__fmul_rn((float)(m % res), inv), half);     // x fastest (uv.flip(0), :44)
+        const float yc = __fadd_rn(__fmul_rn((float)(m / res), inv), half);
+        float xl = __fadd_rn(__fsub_rn(xc, cx), __fdiv_rn(__fmul_rn(cy, sk), fy));
+        xl = __fdiv_rn(__fsub_rn(xl, __fdiv_rn(__fmul_rn(sk, yc), fy)), fx);      // :51
+        const float yl = __fdiv_rn(__fsub_rn(yc, cy), fy);                        // :52
+        float d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float wpt = __builtin_fmaf(C[k * 4 + 0], xl, __builtin_fmaf(C[k * 4 + 1], yl, C[k * 4 + 2])) + C[k * 4 + 3];
+            d[k] = __fsub_rn(wpt, C[k * 4 + 3]);                                  // world - cam_loc, :58
+        }
+        const float nrm = fmaxf((float)sqrt((double)d[0] * d[0] + (double)d[1] * d[1] + (double)d[2] * d[2]), 1e-12f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            d_out[idx * 3 + k] = __fdiv_rn(d[k], nrm);                            // F.normalize, :59
+            o_out[idx * 3 + k] = C[k * 4 + 3];
+        }
+    }
+}
+
+__global__ void ray_limits_box_kernel(const float *__restrict__ o, const float *__restrict__ d, int64_t n, float half,
+                                      float *__restrict__ tmin_out, float *__restrict__ tmax_out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float lo[3], hi[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float inv = __fdiv_rn(1.f, d[i * 3 + k]);
+            const bool neg = inv < 0.f;
+            lo[k] = __fmul_rn(__fsub_rn(neg ? half : -half, o[i * 3 + k]), inv);
+            hi[k] = __fmul_rn(__fsub_rn(neg ? -half : half, o[i * 3 + k]), inv);
+        }
+        bool valid = !(lo[0] > hi[1] || lo[1] > hi[0]);
+        // torch.max/min propagate NaN; fmaxf would drop it -- keep torch's semantics
+        auto tmax2 = [](float a, float b) { return (isnan(a) || isnan(b)) ? NAN : fmaxf(a, b); };
+        auto tmin2 = [](float a, float b) { return (isnan(a) || isnan(b)) ? NAN : fminf(a, b); };
+        float tmin = tmax2(lo[0], lo[1]), tmax = tmin2(hi[0], hi[1]);
+        if (tmin > hi[2] || lo[2] > tmax) valid = false;
+        tmin = tmax2(tmin, lo[2]);
+        tmax = tmin2(tmax, hi[2]);
+        tmin_out[i] = valid ? tmin : -1.f;
+        tmax_out[i] = valid ? tmax : -2.f;
+    }
+}
+
+static inline int grid_for(int64_t total, int block) {
+    int64_t g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+static inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+}  // namespace nerfmi
+
+using namespace nerfmi;
+
+extern "C" {
+
+int nerfmi_eg3d_pack_planes(const float *planes_nchw, int n_planes, int channels, int h, int w, float *planes_hwc,
+                            nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_planes >= 1 && channels == EC && h >= 1 && w >= 1, "eg3d_pack_planes: need %d channels, got %d", EC, channels);
+    NERFMI_REQUIRE(planes_nchw && planes_hwc, "eg3d_pack_planes: null pointer");
+    const int64_t total = (int64_t)n_planes * channels * h * w;
+    hipLaunchKernelGGL(pack_planes_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, planes_nchw,
+                       (int64_t)n_planes, channels, h, w, planes_hwc);
+    return check_launch("eg3d_pack_planes");
+}
+
+size_t nerfmi_eg3d_decoder_floats(void) { return (size_t)DEC_FLOATS; }
+
+int nerfmi_eg3d_pack_decoder(const float *w0, const float *b0, const float *w1, const float *b1, float lr_multiplier,
+                             float *packed, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(w0 && b0 && w1 && b1 && packed, "eg3d_pack_decoder: null pointer");
+    hipLaunchKernelGGL(pack_decoder_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w0, b0, w1, b1, lr_multiplier, packed);
+    return check_launch("eg3d_pack_decoder");
+}
+
+int nerfmi_eg3d_sample_planes(const float *planes_hwc, int n, int h, int w, const float *coords, int64_t n_points,
+                              float box_warp, float *feats_out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n >= 1 && h >= 1 && w >= 1 && n_points >= 0 && box_warp != 0.f, "eg3d_sample_planes: bad sizes");
+    if (n_points == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(planes_hwc && coords && feats_out, "eg3d_sample_planes: null pointer");
+    const float scale = (float)(2.0 / (double)box_warp);
+    hipLaunchKernelGGL((triplane_kernel<0, false>), dim3(grid_for((int64_t)n * n_points, 256)), dim3(256), 0,
+                       (hipStream_t)stream, planes_hwc, n, h, w, coords, nullptr, nullptr, nullptr, 1, n_points, scale,
+                       nullptr, feats_out, nullptr, nullptr);
+    return check_launch("eg3d_sample_planes");
+}
+
+int nerfmi_eg3d_run_model(const float *planes_hwc, int n, int h, int w, const float *decoder_packed,
+                          const float *coords, int64_t n_points, float box_warp, float *rgb_out, float *sigma_out,
+                          nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n >= 1 && h >= 1 && w >= 1 && n_points >= 0 && box_warp != 0.f, "eg3d_run_model: bad sizes");
+    if (n_points == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(planes_hwc && decoder_packed && coords && rgb_out && sigma_out, "eg3d_run_model: null pointer");
+    const float scale = (float)(2.0 / (double)box_warp);
+    hipLaunchKernelGGL((triplane_kernel<1, false>), dim3(grid_for((int64_t)n * n_points, 256)), dim3(256), 0,
+                       (hipStream_t)stream, planes_hwc, n, h, w, coords, nullptr, nullptr, nullptr, 1, n_points, scale,
+                       decoder_packed, nullptr, rgb_out, sigma_out);
+    return check_launch("eg3d_run_model");
+}
+
+int nerfmi_eg3d_run_model_rays(const float *planes_hwc, int n, int h, int w, const float *decoder_packed,
+                               const float *ray_origins, const float *ray_directions, const float *depths,
+                               int64_t n_rays_per_batch, int n_samples, float box_warp, float *rgb_out,
+                               float *sigma_out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n >= 1 && h >= 1 && w >= 1 && n_rays_per_batch >= 0 && n_samples >= 1 && box_warp != 0.f,
+                   "eg3d_run_model_rays: bad sizes");
+    const int64_t P = n_rays_per_batch * n_samples;
+    if (P == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(planes_hwc && decoder_packed && ray_origins && ray_directions && depths && rgb_out && sigma_out,
+                   "eg3d_run_model_rays: null pointer");
+    const float scale = (float)(2.0 / (double)box_warp);
+    hipLaunchKernelGGL((triplane_kernel<1, true>), dim3(grid_for((int64_t)n * P, 256)), dim3(256), 0, (hipStream_t)stream,
+                       planes_hwc, n, h, w, nullptr, ray_origins, ray_directions, depths, n_samples, P, scale,
+                       decoder_packed, nullptr, rgb_out, sigma_out);
+    return check_launch("eg3d_run_model_rays");
+}
+
+int nerfmi_eg3d_sample_stratified(const float *ray_start_t, const float *ray_end_t, float ray_start, float ray_end,
+                                  const float *rand, int64_t n_rays, int n_samples, int disparity, float *depths_out,
+                                  nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 2, "eg3d_sample_stratified: bad sizes");
+    if (n_rays == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(rand && depths_out, "eg3d_sample_stratified: null pointer");
+    NERFMI_REQUIRE((ray_start_t == nullptr) == (ray_end_t == nullptr), "eg3d_sample_stratified: start/end tensors come in pairs");
+    float s = ray_start, e = ray_end, delta;
+    if (disparity) {
+        delta = (float)(1.0 / (n_samples - 1));
+        s = (float)(1.0 / (double)ray_start);
+        e = (float)(1.0 / (double)ray_end);
+    } else {
+        delta = (float)(((double)ray_end - (double)ray_start) / (n_samples - 1));
+    }
+    hipLaunchKernelGGL(eg3d_stratified_kernel, dim3(grid_for(n_rays * n_samples, 256)), dim3(256), 0, (hipStream_t)stream,
+                       ray_start_t, ray_end_t, s, e, delta, rand, n_rays, n_samples, disparity, depths_out);
+    return check_launch("eg3d_sample_stratified");
+}
+
+int nerfmi_eg3d_minmax(const float *x, int64_t n, float *minmax_out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n >= 1 && x && minmax_out, "eg3d_minmax: bad arguments");
+    hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, minmax_out);
+    return check_launch("eg3d_minmax");
+}
+
+int nerfmi_eg3d_march(const float *colors, const float *densities, const float *depths, const float *minmax,
+                      int64_t n_rays, int n_samples, int white_back, float *rgb_out, float *depth_out,
+                      float *weights_out, float *weight_sum_out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 2 && n_samples <= 1025, "eg3d_march: n_samples=%d out of [2,1025]", n_samples);
+    if (n_rays == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(colors && densities && depths && minmax && rgb_out && depth_out, "eg3d_march: null pointer");
+    const dim3 grid((unsigned)(n_rays < 65536 ? n_rays : 65536)), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    const int spl = (n_samples - 1 + 63) / 64;
+#define CALL(SPL) hipLaunchKernelGGL((mip_march_kernel<SPL>), grid, block, 0, st, colors, densities, depths, minmax, \
+                                     n_rays, n_samples, white_back, rgb_out, depth_out, weights_out, weight_sum_out)
+    if (spl <= 1) CALL(1); else if (spl <= 2) CALL(2); else if (spl <= 4) CALL(4); else if (spl <= 8) CALL(8); else CALL(16);
+#undef CALL
+    return check_launch("eg3d_march");
+}
+
+int nerfmi_eg3d_sample_importance(const float *depths, const float *weights, const float *u, int64_t n_rays,
+                                  int n_samples, int n_importance, float *z_out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 4 && n_samples <= 4096 && n_importance >= 1, "eg3d_sample_importance: bad sizes");
+    if (n_rays == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(depths && weights && u && z_out, "eg3d_sample_importance: null pointer");
+    const size_t lds = sizeof(float) * (3 * (size_t)n_samples + 8);
+    hipLaunchKernelGGL(eg3d_importance_kernel, dim3((unsigned)(n_rays < 65536 ? n_rays : 65536)), dim3(64), lds,
+                       (hipStream_t)stream, depths, weights, u, n_rays, n_samples, n_importance, z_out);
+    return check_launch("eg3d_sample_importance");
+}
+
+int nerfmi_eg3d_unify(const float *d1, const float *c1, const float *s1, const float *d2, const float *c2,
+                      const float *s2, int64_t n_rays, int n1, int n2, float *d_out, float *c_out, float *s_out,
+                      nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_rays >= 0 && n1 >= 1 && n2 >= 0 && n1 + n2 <= 8192, "eg3d_unify: bad sizes");
+    if (n_rays == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(d1 && c1 && s1 && (n2 == 0 || (d2 && c2 && s2)) && d_out && c_out && s_out, "eg3d_unify: null pointer");
+    const int npad = next_pow2(n1 + n2 < 2 ? 2 : n1 + n2);
+    hipLaunchKernelGGL(eg3d_unify_kernel, dim3((unsigned)(n_rays < 65536 ? n_rays : 65536)), dim3(64),
+                       sizeof(float) * 2 * npad, (hipStream_t)stream, d1, c1, s1, d2, c2, s2, n_rays, n1, n2, npad, d_out,
+                       c_out, s_out);
+    return check_launch("eg3d_unify");
+}
+
+int nerfmi_eg3d_ray_sampler(const float *cam2world, const float *intrinsics, int n, int resolution, float *origins_out,
+                            float *dirs_out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n >= 0 && resolution >= 1, "eg3d_ray_sampler: bad sizes");
+    if (n == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(cam2world && intrinsics && origins_out && dirs_out, "eg3d_ray_sampler: null pointer");
+    hipLaunchKernelGGL(ray_sampler_kernel, dim3(grid_for((int64_t)n * resolution * resolution, 256)), dim3(256), 0,
+                       (hipStream_t)stream, cam2world, intrinsics, n, resolution, origins_out, dirs_out);
+    return check_launch("eg3d_ray_sampler");
+}
+
+int nerfmi_eg3d_ray_limits_box(const float *rays_o, const float *rays_d, int64_t n, float box_side_length,
+                               float *tmin_out, float *tmax_out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n >= 0, "eg3d_ray_limits_box: bad size");
+    if (n == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(rays_o && rays_d && tmin_out && tmax_out, "eg3d_ray_limits_box: null pointer");
+    hipLaunchKernelGGL(ray_limits_box_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, n,
+                       (float)((double)box_side_length / 2.0), tmin_out, tmax_out);
+    return check_launch("eg3d_ray_limits_box");
+}
+
+}  // extern "C"

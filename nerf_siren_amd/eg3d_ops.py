@@ -1,0 +1,152 @@
+"""Tensor-level wrappers over the EG3D part of the C ABI (include/nerfmi.h)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+from .ops import _req, _stream
+
+
+def pack_planes(planes):
+    """(N,3,32,H,W) NCHW -> channels-last (N*3,H,W,32) image used by every EG3D kernel."""
+    planes = _req(planes, "planes", (None, 3, 32, None, None))
+    n, _, c, h, w = planes.shape
+    out = torch.empty((n * 3, h, w, c), device=planes.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_pack_planes(ptr(planes), n * 3, c, h, w, ptr(out), _stream(planes)), "eg3d_pack_planes")
+    return out
+
+
+def pack_decoder(w0, b0, w1, b1, lr_mul=1.0):
+    w0, b0 = _req(w0.detach(), "net.0.weight", (64, 32)), _req(b0.detach(), "net.0.bias", (64,))
+    w1, b1 = _req(w1.detach(), "net.2.weight", (4, 64)), _req(b1.detach(), "net.2.bias", (4,))
+    out = torch.empty(_lib.lib().nerfmi_eg3d_decoder_floats(), device=w0.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_pack_decoder(ptr(w0), ptr(b0), ptr(w1), ptr(b1), float(lr_mul), ptr(out), _stream(w0)),
+          "eg3d_pack_decoder")
+    return out
+
+
+def sample_planes(planes_hwc, n, coords, box_warp):
+    coords = _req(coords, "coordinates", (n, None, 3))
+    p = coords.shape[1]
+    h, w = planes_hwc.shape[1], planes_hwc.shape[2]
+    out = torch.empty((n, 3, p, 32), device=coords.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_sample_planes(ptr(planes_hwc), n, h, w, ptr(coords), p, float(box_warp), ptr(out),
+                                               _stream(coords)), "eg3d_sample_planes")
+    return out
+
+
+def run_model(planes_hwc, n, dec, coords, box_warp):
+    coords = _req(coords, "coordinates", (n, None, 3))
+    p = coords.shape[1]
+    h, w = planes_hwc.shape[1], planes_hwc.shape[2]
+    rgb = torch.empty((n, p, 3), device=coords.device, dtype=torch.float32)
+    sigma = torch.empty((n, p, 1), device=coords.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_run_model(ptr(planes_hwc), n, h, w, ptr(dec), ptr(coords), p, float(box_warp), ptr(rgb),
+                                           ptr(sigma), _stream(coords)), "eg3d_run_model")
+    return rgb, sigma
+
+
+def run_model_rays(planes_hwc, n, dec, ray_o, ray_d, depths, box_warp):
+    ray_o = _req(ray_o, "ray_origins", (n, None, 3))
+    m = ray_o.shape[1]
+    ray_d = _req(ray_d, "ray_directions", (n, m, 3))
+    depths = _req(depths.reshape(n, m, -1), "depths")
+    s = depths.shape[2]
+    h, w = planes_hwc.shape[1], planes_hwc.shape[2]
+    rgb = torch.empty((n, m, s, 3), device=ray_o.device, dtype=torch.float32)
+    sigma = torch.empty((n, m, s, 1), device=ray_o.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_run_model_rays(ptr(planes_hwc), n, h, w, ptr(dec), ptr(ray_o), ptr(ray_d), ptr(depths),
+                                                m, s, float(box_warp), ptr(rgb), ptr(sigma), _stream(ray_o)),
+          "eg3d_run_model_rays")
+    return rgb, sigma
+
+
+def sample_stratified(n_rays, n_samples, rand, ray_start, ray_end, disparity=False):
+    rand = _req(rand.reshape(n_rays, n_samples), "rand")
+    out = torch.empty((n_rays, n_samples), device=rand.device, dtype=torch.float32)
+    if isinstance(ray_start, torch.Tensor):
+        st = _req(ray_start.reshape(n_rays), "ray_start")
+        en = _req(ray_end.reshape(n_rays), "ray_end")
+        check(_lib.lib().nerfmi_eg3d_sample_stratified(ptr(st), ptr(en), 0.0, 0.0, ptr(rand), n_rays, n_samples, 0,
+                                                       ptr(out), _stream(rand)), "eg3d_sample_stratified")
+    else:
+        check(_lib.lib().nerfmi_eg3d_sample_stratified(None, None, float(ray_start), float(ray_end), ptr(rand), n_rays,
+                                                       n_samples, int(bool(disparity)), ptr(out), _stream(rand)),
+              "eg3d_sample_stratified")
+    return out
+
+
+def minmax(x):
+    x = _req(x.reshape(-1), "depths")
+    out = torch.empty(2, device=x.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_minmax(ptr(x), x.numel(), ptr(out), _stream(x)), "eg3d_minmax")
+    return out
+
+
+def march(colors, densities, depths, white_back=False, mm=None):
+    """colors (R,S,3), densities (R,S), depths (R,S) -> rgb (R,3), depth (R), weights (R,S-1), weight_sum (R)."""
+    colors = _req(colors, "colors", (None, None, 3))
+    r, s = colors.shape[0], colors.shape[1]
+    densities = _req(densities.reshape(r, s), "densities")
+    depths = _req(depths.reshape(r, s), "depths")
+    if mm is None:
+        mm = minmax(depths)
+    dev = colors.device
+    rgb = torch.empty((r, 3), device=dev, dtype=torch.float32)
+    depth = torch.empty((r,), device=dev, dtype=torch.float32)
+    w = torch.empty((r, s - 1), device=dev, dtype=torch.float32)
+    ws = torch.empty((r,), device=dev, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_march(ptr(colors), ptr(densities), ptr(depths), ptr(mm), r, s, int(bool(white_back)),
+                                       ptr(rgb), ptr(depth), ptr(w), ptr(ws), _stream(colors)), "eg3d_march")
+    return rgb, depth, w, ws
+
+
+def sample_importance(depths, weights, u):
+    depths = _req(depths, "z_vals", (None, None))
+    r, s = depths.shape
+    weights = _req(weights.reshape(r, s - 1), "weights")
+    u = _req(u, "u", (r, None))
+    f = u.shape[1]
+    out = torch.empty((r, f), device=depths.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_sample_importance(ptr(depths), ptr(weights), ptr(u), r, s, f, ptr(out), _stream(depths)),
+          "eg3d_sample_importance")
+    return out
+
+
+def unify(d1, c1, s1, d2, c2, s2):
+    d1 = _req(d1, "depths1", (None, None))
+    r, n1 = d1.shape
+    d2 = _req(d2.reshape(r, -1), "depths2")
+    n2 = d2.shape[1]
+    c1, s1 = _req(c1.reshape(r, n1, 3), "colors1"), _req(s1.reshape(r, n1), "densities1")
+    c2, s2 = _req(c2.reshape(r, n2, 3), "colors2"), _req(s2.reshape(r, n2), "densities2")
+    dev = d1.device
+    d = torch.empty((r, n1 + n2), device=dev, dtype=torch.float32)
+    c = torch.empty((r, n1 + n2, 3), device=dev, dtype=torch.float32)
+    s = torch.empty((r, n1 + n2), device=dev, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_unify(ptr(d1), ptr(c1), ptr(s1), ptr(d2), ptr(c2), ptr(s2), r, n1, n2, ptr(d), ptr(c),
+                                       ptr(s), _stream(d1)), "eg3d_unify")
+    return d, c, s
+
+
+def ray_sampler(cam2world, intrinsics, resolution):
+    cam2world = _req(cam2world, "cam2world_matrix", (None, 4, 4))
+    n = cam2world.shape[0]
+    intrinsics = _req(intrinsics, "intrinsics", (n, 3, 3))
+    o = torch.empty((n, resolution * resolution, 3), device=cam2world.device, dtype=torch.float32)
+    d = torch.empty_like(o)
+    check(_lib.lib().nerfmi_eg3d_ray_sampler(ptr(cam2world), ptr(intrinsics), n, int(resolution), ptr(o), ptr(d),
+                                             _stream(cam2world)), "eg3d_ray_sampler")
+    return o, d
+
+
+def ray_limits_box(rays_o, rays_d, box_side_length):
+    shp = rays_o.shape
+    o = _req(rays_o.detach().reshape(-1, 3), "rays_o")
+    d = _req(rays_d.detach().reshape(-1, 3), "rays_d")
+    tmin = torch.empty(o.shape[0], device=o.device, dtype=torch.float32)
+    tmax = torch.empty_like(tmin)
+    check(_lib.lib().nerfmi_eg3d_ray_limits_box(ptr(o), ptr(d), o.shape[0], float(box_side_length), ptr(tmin), ptr(tmax),
+                                                _stream(o)), "eg3d_ray_limits_box")
+    return tmin.reshape(*shp[:-1], 1), tmax.reshape(*shp[:-1], 1)

@@ -1,0 +1,134 @@
+"""volumetric_rendering/renderer.py:23-256 (ImportanceRenderer and helpers) on the gfx950 kernels.
+
+Forward only this round: the reference's backward (grads to planes / decoder) is not implemented, so the
+renderer raises if called with grad-requiring inputs while grad is enabled.
+rendering_options may carry two extra keys to inject the reference's random draws (parity tests):
+'rng_stratified' (N,M,S,1) = the rand_like of sample_stratified, 'rng_importance' (N*M,F) = the rand of sample_pdf.
+"""
+import torch
+
+from .. import eg3d_ops
+from .ray_marcher import MipRayMarcher2
+from . import math_utils
+
+
+def generate_planes():
+    """renderer.py:23-37."""
+    return torch.tensor([[[1, 0, 0], [0, 1, 0], [0, 0, 1]],
+                         [[1, 0, 0], [0, 0, 1], [0, 1, 0]],
+                         [[0, 0, 1], [1, 0, 0], [0, 1, 0]]], dtype=torch.float32)
+
+
+def project_onto_planes(planes, coordinates):
+    """renderer.py:39-53: (N,M,3) -> (N*n_planes, M, 2).  With the reference's plane axes the projection is a
+    coordinate selection: (x,y), (x,z), (z,x) -- which is what the fused kernel applies."""
+    x, y, z = coordinates[..., 0], coordinates[..., 1], coordinates[..., 2]
+    sel = torch.stack([torch.stack([x, y], -1), torch.stack([x, z], -1), torch.stack([z, x], -1)], 1)
+    return sel.reshape(coordinates.shape[0] * 3, coordinates.shape[1], 2)
+
+
+def sample_from_planes(plane_axes, plane_features, coordinates, mode='bilinear', padding_mode='zeros', box_warp=None):
+    """renderer.py:55-65: plane_features (N,3,C,H,W), coordinates (N,M,3) -> (N,3,M,C)."""
+    assert padding_mode == 'zeros'
+    assert mode == 'bilinear'
+    n = plane_features.shape[0]
+    return eg3d_ops.sample_planes(eg3d_ops.pack_planes(plane_features), n, coordinates, box_warp)
+
+
+class ImportanceRenderer(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.ray_marcher = MipRayMarcher2()
+        self.plane_axes = generate_planes()
+        self._planes_key = None
+        self._planes_hwc = None
+
+    def _pack(self, planes):
+        key = (planes.data_ptr(), planes._version, tuple(planes.shape))
+        if key != self._planes_key:
+            self._planes_hwc = eg3d_ops.pack_planes(planes)
+            self._planes_key = key
+        return self._planes_hwc
+
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
+        """-> rgb_coarse (N,M,3), depth_coarse (N,M,1), weights_coarse.sum(2) (N,M,1), rgb_final, depth_final,
+        weights.sum(2)  (renderer.py:88-142)."""
+        if torch.is_grad_enabled() and (planes.requires_grad or any(p.requires_grad for p in decoder.parameters())):
+            raise NotImplementedError("ImportanceRenderer backward (grads to planes/decoder) is not implemented yet; "
+                                      "call under torch.no_grad()")
+        opts = rendering_options
+        N, M, _ = ray_origins.shape
+        S = opts['depth_resolution']
+        dev = ray_origins.device
+        rs = opts.get('rng_stratified')
+        rs = torch.rand((N * M, S), device=dev) if rs is None else rs.reshape(N * M, S)
+        if opts['ray_start'] == opts['ray_end'] == 'auto':
+            ray_start, ray_end = math_utils.get_ray_limits_box(ray_origins, ray_directions, box_side_length=opts['box_warp'])
+            is_ray_valid = ray_end > ray_start
+            if torch.any(is_ray_valid).item():                                   # renderer.py:93-95
+                ray_start[~is_ray_valid] = ray_start[is_ray_valid].min()
+                ray_end[~is_ray_valid] = ray_start[is_ray_valid].max()
+            depths_coarse = eg3d_ops.sample_stratified(N * M, S, rs, ray_start, ray_end)
+        else:
+            depths_coarse = eg3d_ops.sample_stratified(N * M, S, rs, opts['ray_start'], opts['ray_end'],
+                                                       opts.get('disparity_space_sampling', False))
+        planes_hwc = self._pack(planes)
+        dec = decoder.packed()
+        wb = opts.get('white_back', False)
+        o, d = ray_origins.contiguous(), ray_directions.contiguous()
+
+        colors_coarse, dens_coarse = eg3d_ops.run_model_rays(planes_hwc, N, dec, o, d, depths_coarse, opts['box_warp'])
+        if opts.get('density_noise', 0) > 0:                                     # renderer.py:149-150
+            dens_coarse = dens_coarse + torch.randn_like(dens_coarse) * opts['density_noise']
+        cc = colors_coarse.reshape(N * M, S, 3)
+        sc = dens_coarse.reshape(N * M, S)
+        rgb_coarse, depth_coarse, weights_coarse, wsum_coarse = eg3d_ops.march(cc, sc, depths_coarse, wb)
+
+        F = opts['depth_resolution_importance']
+        if F <= 0:
+            raise SystemExit                                                     # the reference calls exit() (renderer.py:139)
+        u = opts.get('rng_importance')
+        u = torch.rand((N * M, F), device=dev) if u is None else u.reshape(N * M, F)
+        depths_fine = eg3d_ops.sample_importance(depths_coarse, weights_coarse, u)
+        colors_fine, dens_fine = eg3d_ops.run_model_rays(planes_hwc, N, dec, o, d, depths_fine, opts['box_warp'])
+        if opts.get('density_noise', 0) > 0:
+            dens_fine = dens_fine + torch.randn_like(dens_fine) * opts['density_noise']
+        all_d, all_c, all_s = eg3d_ops.unify(depths_coarse, cc, sc, depths_fine, colors_fine.reshape(N * M, F, 3),
+                                             dens_fine.reshape(N * M, F))
+        rgb_final, depth_final, _, wsum = eg3d_ops.march(all_c, all_s, all_d, wb)
+        v = lambda t, c: t.view(N, M, c)
+        return (v(rgb_coarse, 3), v(depth_coarse, 1), v(wsum_coarse, 1), v(rgb_final, 3), v(depth_final, 1), v(wsum, 1))
+
+    def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
+        """renderer.py:144-151 -> {'rgb': (N,M,3), 'sigma': (N,M,1)}."""
+        n = planes.shape[0]
+        rgb, sigma = eg3d_ops.run_model(self._pack(planes), n, decoder.packed(), sample_coordinates, options['box_warp'])
+        if options.get('density_noise', 0) > 0:
+            sigma = sigma + torch.randn_like(sigma) * options['density_noise']
+        return {'rgb': rgb, 'sigma': sigma}
+
+    def unify_samples(self, depths1, colors1, densities1, depths2, colors2, densities2):
+        """renderer.py:160-170; (N,M,S,.) tensors."""
+        n, m = depths1.shape[0], depths1.shape[1]
+        s1, s2 = depths1.shape[2], depths2.shape[2]
+        d, c, s = eg3d_ops.unify(depths1.reshape(n * m, s1), colors1.reshape(n * m, s1, 3), densities1.reshape(n * m, s1),
+                                 depths2.reshape(n * m, s2), colors2.reshape(n * m, s2, 3), densities2.reshape(n * m, s2))
+        return d.view(n, m, s1 + s2, 1), c.view(n, m, s1 + s2, 3), s.view(n, m, s1 + s2, 1)
+
+    sort_samples = None  # the reference's sort_samples (renderer.py:153-158) has no caller
+
+    def sample_stratified(self, ray_origins, ray_start, ray_end, depth_resolution, disparity_space_sampling=False,
+                          rand=None):
+        """renderer.py:172-195 -> (N,M,S,1)."""
+        N, M, _ = ray_origins.shape
+        rs = torch.rand((N * M, depth_resolution), device=ray_origins.device) if rand is None else rand
+        return eg3d_ops.sample_stratified(N * M, depth_resolution, rs, ray_start, ray_end,
+                                          disparity_space_sampling).view(N, M, depth_resolution, 1)
+
+    def sample_importance(self, z_vals, weights, N_importance, u=None):
+        """renderer.py:197-215 -> (N,M,N_importance,1)."""
+        n, m, s, _ = z_vals.shape
+        if u is None:
+            u = torch.rand((n * m, N_importance), device=z_vals.device)
+        out = eg3d_ops.sample_importance(z_vals.reshape(n * m, s), weights.reshape(n * m, s - 1), u)
+        return out.view(n, m, N_importance, 1)

@@ -466,3 +466,111 @@ def test_siren_render_rays(dev, siren, ops):
     assert torch.isfinite(res["rgb_fine"]).all() and (res["opacity_fine"] <= 1 + 1e-5).all()
     with pytest.raises(NotImplementedError):
         render_rays([f, f], emb, T(rays, dev), 64, False, 0, 0, 64, 1024 * 32, True, False)   # grad mode
+
+
+# --------------------------------------------------------------------------- EG3D (a9-a14)
+from oracle import eg3d_oracle as EO  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def osg(dev):
+    from nerf_siren_amd import OSGDecoder
+    dec = OSGDecoder(32, {"decoder_lr_mul": 1.0, "decoder_output_dim": 3})
+    r = dec.load_state_dict({k: torch.from_numpy(v) for k, v in synth.osg_params(4).items()})
+    assert not r.missing_keys and not r.unexpected_keys
+    return dec.to(dev)
+
+
+def test_eg3d_run_model(golden, dev, osg):
+    from nerf_siren_amd.volumetric_rendering import ImportanceRenderer, generate_planes, sample_from_planes
+    g = golden("g9_eg3d_run_model")
+    planes = T(synth.triplanes(5, res=16), dev)
+    feats = N(sample_from_planes(generate_planes(), planes, T(g["coords"], dev), padding_mode="zeros", box_warp=15.0))
+    np.testing.assert_allclose(feats, g["feats"], atol=2e-6, rtol=1e-6)
+    assert np.array_equal(feats, EO.sample_from_planes(synth.triplanes(5, res=16), g["coords"], 15.0))   # same arithmetic
+    out = ImportanceRenderer().run_model(planes, osg, T(g["coords"], dev), None, {"box_warp": 15.0})
+    np.testing.assert_allclose(N(out["rgb"]), g["rgb"], atol=3e-6)
+    np.testing.assert_allclose(N(out["sigma"]), g["sigma"], atol=3e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("wb", [0, 1])
+def test_eg3d_marcher(golden, dev, wb):
+    from nerf_siren_amd import MipRayMarcher2
+    g = golden(f"g10_eg3d_march_wb{wb}")
+    rgb, depth, w = MipRayMarcher2()(T(g["colors"], dev), T(g["densities"], dev), T(g["depths"], dev),
+                                     {"clamp_mode": "softplus", "white_back": bool(wb)})
+    np.testing.assert_allclose(N(w), g["weights"], atol=2.4e-7, rtol=1e-6)
+    np.testing.assert_allclose(N(rgb), g["rgb"], atol=1e-6)
+    np.testing.assert_allclose(N(depth), g["depth"], atol=5e-6, rtol=1e-6)
+    r2, d2, w2 = EO.mip_march(g["colors"], g["densities"], g["depths"], bool(wb))
+    assert (N(w) == w2).mean() > 0.999
+    with pytest.raises(AssertionError):
+        MipRayMarcher2()(T(g["colors"], dev), T(g["densities"], dev), T(g["depths"], dev), {"clamp_mode": "mip"})
+
+
+def test_eg3d_importance_and_unify(golden, dev):
+    from nerf_siren_amd import ImportanceRenderer
+    g = golden("g11_eg3d_importance")
+    ren = ImportanceRenderer()
+    zf = N(ren.sample_importance(T(g["depths"], dev), T(g["weights"], dev), 64, u=T(g["u"], dev)))
+    zo, _ = EO.sample_importance(g["depths"], g["weights"], 64, g["u"])
+    assert np.array_equal(zf, zo)                                     # same specified arithmetic -> same bits
+    err = np.abs(zf - g["z_fine"])
+    assert (err < 1e-5).mean() > 0.995 and err.max() < 0.2
+    # unify: sorted depths + gathered payload
+    n, m, s = 1, 37, 64
+    c1, s1 = synth.hash_uniform((n, m, s, 3), 500), synth.hash_normal((n, m, s, 1), 501)
+    c2, s2 = synth.hash_uniform((n, m, 64, 3), 502), synth.hash_normal((n, m, 64, 1), 503)
+    d, c, sg = ren.unify_samples(T(g["depths"], dev), T(c1, dev), T(s1, dev), T(zf, dev), T(c2, dev), T(s2, dev))
+    do, co, so = EO.unify_samples(g["depths"], c1, s1, zf, c2, s2)
+    assert np.array_equal(N(d), do) and np.array_equal(N(c), co) and np.array_equal(N(sg), so)
+
+
+def test_eg3d_forward(golden, dev, osg):
+    from nerf_siren_amd import ImportanceRenderer
+    g = golden("g12_eg3d_forward")
+    planes = T(synth.triplanes(6, res=64), dev)
+    opts = dict(synth.EG3D_OPTIONS, rng_stratified=T(g["rand_strat"], dev), rng_importance=T(g["u"], dev))
+    with torch.no_grad():
+        res = ImportanceRenderer()(planes, osg, T(g["ray_o"][None], dev), T(g["ray_d"][None], dev), opts)
+    ref = EO.importance_renderer(synth.triplanes(6, res=64), synth.osg_params(4), g["ray_o"][None], g["ray_d"][None],
+                                 synth.EG3D_OPTIONS, g["rand_strat"], g["u"])
+    for k, v, o in zip(("rgb_c", "depth_c", "op_c", "rgb_f", "depth_f", "op_f"), res, ref[:6]):
+        v = N(v)
+        assert v.shape == g[k].shape
+        tol = 1e-4 * (9.9 if "depth" in k else 1.0)
+        for target in (g[k], o):
+            err = np.abs(v - target).reshape(50, -1).max(-1)
+            assert (err <= tol).mean() >= 0.9 and err.max() <= 100 * tol, (k, err.max())
+            if k.endswith("_c"):
+                assert err.max() <= tol, (k, err.max())
+    planes.requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        ImportanceRenderer()(planes, osg, T(g["ray_o"][None], dev), T(g["ray_d"][None], dev), opts)
+
+
+@pytest.mark.parametrize("res", [2, 8])
+def test_eg3d_ray_sampler(golden, dev, res):
+    from nerf_siren_amd import RaySampler
+    g = golden(f"g13_eg3d_raysampler_{res}")
+    o, d = RaySampler()(T(g["cam2world"], dev), T(g["intrinsics"], dev), res)
+    assert np.array_equal(N(o), g["origins"])
+    np.testing.assert_allclose(N(d), g["dirs"], atol=3e-7)
+
+
+def test_eg3d_ray_limits_box_and_auto(golden, dev, osg):
+    from nerf_siren_amd.volumetric_rendering import math_utils, ImportanceRenderer
+    g = golden("g14_eg3d_box")
+    tmin, tmax = math_utils.get_ray_limits_box(T(g["ray_o"], dev), T(g["ray_d"], dev), 2.0)
+    np.testing.assert_allclose(N(tmin), g["tmin"], atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(N(tmax), g["tmax"], atol=1e-6, rtol=1e-6)
+    # 'auto' ray limits branch (renderer.py:91-97) runs end to end
+    planes = T(synth.triplanes(6, res=64), dev)
+    o, d = synth.eg3d_rays(20, 62)
+    opts = dict(synth.EG3D_OPTIONS, ray_start="auto", ray_end="auto", box_warp=3.0)
+    with torch.no_grad():
+        res = ImportanceRenderer()(planes, osg, T(o[None], dev), T(d[None], dev), opts)
+    assert all(torch.isfinite(t).all() for t in res)
+    st = synth.hash_uniform((5,), 600) + 1
+    lin = N(math_utils.linspace(T(st, dev), T(st + 2, dev), 7))
+    np.testing.assert_allclose(lin, st[None] + np.arange(7, dtype=np.float32)[:, None] / 6 * 2, atol=1e-6)
