@@ -193,6 +193,18 @@ def main():
     dt = float(tmax.item())
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc summary (tools/pmc_summary.py);
+    # counters cannot be collected from inside the timed run
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        want = ("siren_forward_kernel<true, false>" if siren else
+                ("nerf_forward_kernel<false, false, true>" if train else "nerf_forward_kernel<false, false, false>"))
+        for k, e in pmc.items():
+            if want in k and "hbm_bytes" in e and B == 1024:
+                traffic = e["hbm_bytes"]
+    except Exception:
+        pass
     flops_per_launch = B * 128 * (FLOP_SIREN if siren else FLOP_FULL)
     achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
 
@@ -212,7 +224,7 @@ def main():
             "rays_per_s": world * B * args.steps / dt,
             "roofline": {"bound": "mfma", "kernel": ("siren_forward_kernel" if siren else "nerf_forward_kernel") + " (fine MLP, 128 samples/ray)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA, "traffic": traffic,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": kern_ms},
         }
         if world == 1 and not args.no_cpu_baseline and not siren:

@@ -127,12 +127,13 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
     const int half = lane >> 5;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t p0 = wave * 32;
-    if (p0 >= n_points) return;
+    // no early exit: the four waves of a workgroup share the weight stream through LDS (barriers); a wave
+    // past the end computes on a clamped point and stores nothing
     const int64_t praw = p0 + (lane & 31);
     const bool ok = praw < n_points;
     const int64_t p = ok ? praw : n_points - 1;
     RowImage S;
-    S.init(saved, wave, SAVED_ROWS, lane, ok);
+    S.init(saved, wave, SAVED_ROWS, lane, ok, p0 < n_points);
 
     f32x16 e[2], de[1];
     if (EMBEDDED) {
@@ -169,14 +170,14 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         store_block(S, S_DEMB, de[0]);
     }
 
-    const float *wl = packed + lane * 4;
+    __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
+    const int wid = threadIdx.x >> 6;
     const float *bias = packed + OFF_BIAS + 4 * half;
     f32x16 h[8], acc[8];
 
     // Stores share the in-order vmcnt queue with the weight loads: a wait for a weight fragment issued
     // after a store also waits for that store's acknowledgement, so the training variant keeps more
     // fragments in flight.
-    constexpr int PFK = SAVE ? 12 : PF_DEFAULT;
     auto no_pre = [](int) { return 0; };
     // ReLU epilogue; in training each finished block goes straight to the tile-major image
     unsigned mk[4] = {0u, 0u, 0u, 0u};
@@ -195,15 +196,15 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         for (int b = 0; b < 8; ++b) h[b] = acc[b];
     };
 
-    layer_mfma<2, 0, 8, PFK>(wl + OFF_L1, bias, e, nullptr, acc, no_pre, relu_epi(S_H));
+    layer_mfma_lds<2, 0, 8>(packed + OFF_L1, bias, e, nullptr, acc, no_pre, relu_epi(S_H), wlds, wid, lane);
     if (SAVE) store_mask(S, 0, mk);
     copy8();
     for (int l = 1; l <= 3; ++l) {
-        layer_mfma<8, 0, 8, PFK>(wl + OFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, relu_epi(S_H + 256 * l));
+        layer_mfma_lds<8, 0, 8>(packed + OFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, relu_epi(S_H + 256 * l), wlds, wid, lane);
         if (SAVE) store_mask(S, l, mk);
         copy8();
     }
-    layer_mfma<2, 8, 8, PFK>(wl + OFF_L5, bias + 256 * 4, e, h, acc, no_pre, relu_epi(S_H + 256 * 4));
+    layer_mfma_lds<2, 8, 8>(packed + OFF_L5, bias + 256 * 4, e, h, acc, no_pre, relu_epi(S_H + 256 * 4), wlds, wid, lane);
     if (SAVE) store_mask(S, 4, mk);
     copy8();
 
@@ -215,7 +216,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         }
         const bool last = (l == 8);
         const int row0 = last ? S_FINAL : S_H + 256 * l;
-        layer_mfma<8, 0, 8, PFK>(wl + OFF_L6 + (l - 5) * SZ_HID, bias + 256 * l, h, nullptr, acc,
+        layer_mfma_lds<8, 0, 8>(packed + OFF_L6 + (l - 5) * SZ_HID, bias + 256 * l, h, nullptr, acc,
                             no_pre, [&S, &mk, row0, last](int jb, int q, f32x4 c, int) {
                                 if (!last) c = relu4(c);
                                 if (SAVE) {
@@ -223,7 +224,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
                                     store_slice(S, row0 + 32 * jb, q, c);
                                 }
                                 return c;
-                            });
+                            }, wlds, wid, lane);
         if (SAVE && !last) store_mask(S, l, mk);
         copy8();
     }
@@ -232,7 +233,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         return;
     }
     f32x16 dh[4];
-    layer_mfma<8, 1, 4, PFK>(wl + OFF_DIR, packed + OFF_BIAS_DIR + 4 * half, h, de, dh, no_pre, relu_epi(S_DIRH));
+    layer_mfma_lds<8, 1, 4>(packed + OFF_DIR, packed + OFF_BIAS_DIR + 4 * half, h, de, dh, no_pre, relu_epi(S_DIRH), wlds, wid, lane);
     if (SAVE) store_mask(S, 8, mk);
     float rgb[3];
 #pragma unroll
@@ -245,7 +246,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2]; o.w = sigma;
         reinterpret_cast<float4 *>(out)[p] = o;
     }
-    if (SAVE && half == 0) {
+    if (SAVE && half == 0 && S.live) {
         *S.at(S_RGB + 0) = ok ? rgb[0] : 0.f;
         *S.at(S_RGB + 1) = ok ? rgb[1] : 0.f;
         *S.at(S_RGB + 2) = ok ? rgb[2] : 0.f;

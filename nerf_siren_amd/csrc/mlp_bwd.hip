@@ -37,12 +37,12 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
     const int half = lane >> 5;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t p0 = wave * 32;
-    if (p0 >= n_points) return;
+    const bool live = p0 < n_points;          // no early exit: the workgroup's waves share barriers (layer_mfma_lds)
     const int64_t praw = p0 + (lane & 31);
     const bool ok = praw < n_points;
     RowImage S, Wk;
-    S.init(const_cast<float *>(saved), wave, SAVED_ROWS, lane, ok);
-    Wk.init(work, wave, W_ROWS, lane, ok);
+    S.init(const_cast<float *>(saved), wave, SAVED_ROWS, lane, ok, live);
+    Wk.init(work, wave, W_ROWS, lane, ok, live);
 
     float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) go = reinterpret_cast<const float4 *>(grad_out)[praw];
@@ -54,9 +54,9 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
         for (int c = 0; c < 3; ++c) {
             const float rgb = *S.at(S_RGB + c);
             dpre[c] = g3[c] * rgb * (1.0f - rgb);
-            if (half == 0) *Wk.at(W_DRGB + c) = dpre[c];
+                if (half == 0 && live) *Wk.at(W_DRGB + c) = dpre[c];
         }
-        if (half == 0) *Wk.at(W_DSIG) = go.w;
+        if (half == 0 && live) *Wk.at(W_DSIG) = go.w;
     }
     const float dsig = go.w;
 
@@ -81,19 +81,19 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
         dz[b] = v;
         store_block(Wk, W_DDIR + 32 * b, v);
     }
-    const float *wl = packed + lane * 4;
+    __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
+    const int wid = threadIdx.x >> 6;
     // d final = W_dir[:, :256]^T dZ_dir                          (nerf.py:116-118; no activation on final)
-    constexpr int PFK = 6;
-    layer_mfma<4, 0, 8, PFK>(wl + OFF_TDIR, nullptr, dz, nullptr, acc, [](int) { return 0; },
-                             [&Wk](int jb, int q, f32x4 c, int) {
-                                 store_slice(Wk, W_DFINAL + 32 * jb, q, c);
-                                 return c;
-                             });
+    layer_mfma_lds<4, 0, 8>(packed + OFF_TDIR, nullptr, dz, nullptr, acc, [](int) { return 0; },
+                            [&Wk](int jb, int q, f32x4 c, int) {
+                                store_slice(Wk, W_DFINAL + 32 * jb, q, c);
+                                return c;
+                            }, wlds, wid, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) dz[b] = acc[b];
     // d h8 = W_final^T d final + w_sigma d sigma, masked by h8 > 0 (nerf.py:112-116)
     load_mask(S, 7, mk);
-    layer_mfma<8, 0, 8, PFK>(wl + OFF_TFINAL, nullptr, dz, nullptr, acc, [](int) { return 0; },
+    layer_mfma_lds<8, 0, 8>(packed + OFF_TFINAL, nullptr, dz, nullptr, acc, [](int) { return 0; },
                              [&](int jb, int q, f32x4 c, int) {
                                  const f32x4 w = ldg4(packed + OFF_W_SIGMA + 32 * jb + 8 * q + 4 * half);
 #pragma unroll
@@ -103,20 +103,20 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
                                  }
                                  store_slice(Wk, W_DZ + 7 * 256 + 32 * jb, q, c);
                                  return c;
-                             });
+                             }, wlds, wid, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) dz[b] = acc[b];
     // xyz_encoding_8 .. xyz_encoding_2: d h_{l-1} = W_l[:, hidden]^T dZ_l, masked by h_{l-1} > 0
     for (int li = 7; li >= 1; --li) {
         const int wrow = W_DZ + (li - 1) * 256;
         load_mask(S, li - 1, mk);
-        layer_mfma<8, 0, 8, PFK>(wl + OFF_T2 + (li - 1) * SZ_HID, nullptr, dz, nullptr, acc, [](int) { return 0; },
+        layer_mfma_lds<8, 0, 8>(packed + OFF_T2 + (li - 1) * SZ_HID, nullptr, dz, nullptr, acc, [](int) { return 0; },
                                  [&](int jb, int q, f32x4 c, int) {
 #pragma unroll
                                      for (int t = 0; t < 4; ++t) c[t] = mask_bit(mk, jb, q, t) ? c[t] : 0.f;
                                      store_slice(Wk, wrow + 32 * jb, q, c);
                                      return c;
-                                 });
+                                 }, wlds, wid, lane);
 #pragma unroll
         for (int b = 0; b < 8; ++b) dz[b] = acc[b];
     }

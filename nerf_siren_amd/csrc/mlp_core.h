@@ -103,6 +103,96 @@ __device__ __forceinline__ void layer_mfma(const float *__restrict__ wp, const f
     for (int q = 0; q < 4; ++q) run_slice(JB - 1, q, c_prev, pv_prev);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// layer_mfma_lds: the same layer with the weight stream shared by the workgroup's four waves through LDS.
+//
+// Each wave streaming every fragment from L2 itself (layer_mfma) costs 4x the L1/L2 transactions and caps
+// the prefetch distance at what a register ring can hold (6-12 fragments = 1.5-3k cycles) -- and because a
+// wave's vector-memory operations retire IN ORDER, anything slow in that queue (an activation store, an HBM
+// load) then stalls the next weight wait.  Here the four waves, which all walk the same packed image, fetch
+// a quarter each: the stream is cut into stages of GS fragments (16 KiB); at a stage boundary a wave
+// (1) writes the quarter it loaded ONE boundary ago into LDS slot (s+1)%3, (2) issues the global loads of
+// stage s+2 into 16 VGPRs, (3) passes one barrier, then runs stage s from LDS (ds_read_b128 per four
+// MFMAs).  A load is issued ~4k cycles before its data is touched and ~8k before it is consumed; three
+// slots make one barrier per stage sufficient (slot (s+1)%3 was last read in stage s-2, which every wave
+// finished before the previous barrier).
+// ---------------------------------------------------------------------------------------------------
+constexpr int GS = 16;                     // fragments (1 KiB each) per stage
+constexpr int NSLOT = 3;
+constexpr int WLDS_FLOATS = NSLOT * GS * 256;   // 48 KiB
+
+template <int KB0, int KB1, int JB, class Pre, class Epi>
+__device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, const float *__restrict__ bias,
+                                               const f32x16 *in0, const f32x16 *in1, f32x16 *out, Pre pre, Epi epi,
+                                               float *wlds, int wid, int lane) {
+    constexpr int KBT = KB0 + KB1;
+    constexpr int G = JB * KBT * 4;
+    static_assert(G % GS == 0, "layer image must be a whole number of stages");
+    constexpr int NST = G / GS;
+    const float *gsrc = wbase + (4 * wid) * 256 + lane * 4;        // this wave's quarter of every stage
+    float *ldst = wlds + (4 * wid) * 256 + lane * 4;
+    const float *lsrc = wlds + lane * 4;
+    f32x4 st[4];
+    auto gload = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st[i] = ldg4(gsrc + (stage * GS + i) * 256);
+    };
+    auto lwrite = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(ldst + ((stage % NSLOT) * GS + i) * 256) = st[i];
+    };
+    __syncthreads();                       // every wave is done reading the previous layer's slots
+    gload(0);
+    lwrite(0);
+    if (NST > 1) gload(1);
+    f32x16 c_prev;
+    decltype(pre(0)) pv_prev = pre(0);
+    auto run_slice = [&](int jb, int q, const f32x16 &c, decltype(pre(0)) pv) {
+        const f32x4 o = epi(jb, q, f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}, pv);
+        out[jb][4 * q] = o[0]; out[jb][4 * q + 1] = o[1]; out[jb][4 * q + 2] = o[2]; out[jb][4 * q + 3] = o[3];
+    };
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+        auto pv = (jb == 0) ? pv_prev : pre(jb);
+        f32x16 c;
+        if (bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = ldg4(bias + 32 * jb + 8 * q);
+                c[4 * q + 0] = b[0]; c[4 * q + 1] = b[1]; c[4 * q + 2] = b[2]; c[4 * q + 3] = b[3];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        }
+#pragma unroll
+        for (int kb = 0; kb < KBT; ++kb) {
+            const f32x16 B = (kb < KB0) ? in0[kb] : in1[kb - KB0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = (jb * KBT + kb) * 4 + q;
+                const int stage = g / GS, gl = g % GS;
+                if (gl == 0) {                                   // stage boundary (resolved at compile time)
+                    if (stage + 1 < NST) lwrite(stage + 1);
+                    if (stage + 2 < NST) gload(stage + 2);
+                    __syncthreads();
+                }
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(lsrc + ((stage % NSLOT) * GS + gl) * 256);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], B[4 * q + 0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], B[4 * q + 1], c, 0, 0, 0);
+                const int gq = kb * 4 + q;
+                if (jb > 0 && gq % KBT == KBT / 2) run_slice(jb - 1, gq / KBT, c_prev, pv_prev);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], B[4 * q + 2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], B[4 * q + 3], c, 0, 0, 0);
+            }
+        }
+        c_prev = c;
+        pv_prev = pv;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) run_slice(JB - 1, q, c_prev, pv_prev);
+}
+
 // Activation images kept for training (mlp_layout.h S_* rows, mlp_bwd.hip W_* rows) are TILE-MAJOR:
 // element (row, point p) lives at base[((p/32)*ROWS + row)*32 + p%32].  A wave owns exactly one 32-point
 // tile, so everything it saves is one contiguous ROWS*128-byte region, and the dW GEMM later streams
@@ -136,11 +226,13 @@ struct RowImage {
     int lane;
     unsigned lane_off;   // (4*half + (lane&3))*32 + 4*((lane&31)>>2): unit 4*half+(lane&3), points 4m..4m+3
     bool ok;             // point < n_points (columns beyond n_points are written as 0)
-    __device__ __forceinline__ void init(float *base, int64_t tile_idx, int rows, int lane_, bool ok_) {
-        tile = base + tile_idx * (int64_t)(rows * 32);
+    bool live;           // the wave owns at least one real point (a wave past the end must not store at all)
+    __device__ __forceinline__ void init(float *base, int64_t tile_idx, int rows, int lane_, bool ok_, bool live_) {
+        tile = base + (live_ ? tile_idx : 0) * (int64_t)(rows * 32);
         lane = lane_;
         lane_off = (unsigned)((4 * (lane_ >> 5) + (lane_ & 3)) * 32 + 4 * ((lane_ & 31) >> 2));
         ok = ok_;
+        live = live_;
     }
     // scalar element (row, this lane's point)
     __device__ __forceinline__ float *at(int r) const { return tile + r * 32 + (lane & 31); }
@@ -148,6 +240,7 @@ struct RowImage {
 
 // store registers 4q..4q+3 of a block (units row0 + 8q + 4*half + {0..3}, row0 = block's first row)
 __device__ __forceinline__ void store_slice(const RowImage &im, int row0, int q, f32x4 v) {
+    if (!im.live) return;
     float x[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) x[t] = im.ok ? v[t] : 0.f;
@@ -201,7 +294,8 @@ __device__ __forceinline__ bool mask_bit(const unsigned (&mk)[4], int jb, int q,
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_mask(const RowImage &im, int layer, unsigned (&mk)[4]) {
-    *reinterpret_cast<u32x4 *>(im.tile + (S_MASK + 8 * layer) * 32 + 4 * im.lane) = u32x4{mk[0], mk[1], mk[2], mk[3]};
+    if (im.live)
+        *reinterpret_cast<u32x4 *>(im.tile + (S_MASK + 8 * layer) * 32 + 4 * im.lane) = u32x4{mk[0], mk[1], mk[2], mk[3]};
     mk[0] = mk[1] = mk[2] = mk[3] = 0u;
 }
 __device__ __forceinline__ void load_mask(const RowImage &im, int layer, unsigned (&mk)[4]) {

@@ -67,8 +67,7 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t p0 = wave * 32;
-    if (p0 >= n_points) return;
+    const int64_t p0 = wave * 32;       // no early exit: the workgroup's waves share barriers (layer_mfma_lds)
     const int64_t praw = p0 + (lane & 31);
     const bool ok = praw < n_points;
     const int64_t p = ok ? praw : n_points - 1;
@@ -110,14 +109,15 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
         };
     };
     auto no_pre = [](int) { return 0; };
-    const float *wl = packed + lane * 4;
+    __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
+    const int wid = threadIdx.x >> 6;
     const float *bias = packed + SOFF_BIAS + 4 * half;
     f32x16 h[8], acc[8];
-    layer_mfma<1, 0, 8>(wl + SOFF_L1, bias, e, nullptr, acc, no_pre, film_epi(0));
+    layer_mfma_lds<1, 0, 8>(packed + SOFF_L1, bias, e, nullptr, acc, no_pre, film_epi(0), wlds, wid, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) h[b] = acc[b];
     for (int l = 1; l < 8; ++l) {
-        layer_mfma<8, 0, 8>(wl + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, film_epi(l));
+        layer_mfma_lds<8, 0, 8>(packed + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, film_epi(l), wlds, wid, lane);
 #pragma unroll
         for (int b = 0; b < 8; ++b) h[b] = acc[b];
     }
@@ -126,7 +126,7 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
         if (ok && half == 0) out[p] = sigma;
         return;
     }
-    layer_mfma<1, 8, 8>(wl + SOFF_COLOR, bias + 256 * 8, de, h, acc, no_pre, film_epi(8));            // nerf.py:213
+    layer_mfma_lds<1, 8, 8>(packed + SOFF_COLOR, bias + 256 * 8, de, h, acc, no_pre, film_epi(8), wlds, wid, lane);            // nerf.py:213
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
