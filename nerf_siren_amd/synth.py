@@ -196,3 +196,14 @@ def eg3d_rays(n_rays: int, seed: int = 0, radius: float = 2.7):
     r = blender_rays(n_rays, seed)
     o = (r[:, 0:3] * np.float32(radius / LEGO_RADIUS)).astype(np.float32)
     return o, r[:, 3:6].copy()
+
+
+# ---------------------------------------------------------------------------
+# PSNR-parity protocol (tools/make_psnr_golden.py <-> tests): deterministic batches and random draws
+# ---------------------------------------------------------------------------
+def psnr_batch_indices(step: int, n_total: int, batch: int) -> np.ndarray:
+    return np.minimum((hash_uniform((batch,), 80000 + step) * n_total).astype(np.int64), n_total - 1)
+
+
+def psnr_step_rng(step: int, batch: int, S: int, F: int) -> dict:
+    return {"perturb_rand": hash_uniform((batch, S), 90000 + 4 * step), "u": hash_uniform((batch, F), 90001 + 4 * step)}

@@ -574,3 +574,44 @@ def test_eg3d_ray_limits_box_and_auto(golden, dev, osg):
     st = synth.hash_uniform((5,), 600) + 1
     lin = N(math_utils.linspace(T(st, dev), T(st + 2, dev), 7))
     np.testing.assert_allclose(lin, st[None] + np.arange(7, dtype=np.float32)[:, None] / 6 * 2, atol=1e-6)
+
+
+# --------------------------------------------------------------------------- PSNR parity (metric: "+ PSNR")
+def test_psnr_parity(golden, dev):
+    """Teacher-scene protocol: the same 240 Adam steps the reference ran on CPU
+    (tools/make_psnr_golden.py: same teacher images, same batches, same injected random draws, same
+    initial weights, Adam lr 5e-4) on the HIP path; validation PSNR must agree within 0.1 dB (north_star)."""
+    from nerf_siren_amd import Embedding, NeRF, render_rays
+    g = golden("g15_psnr")
+    S, F, B = int(g["cfg_S"]), int(g["cfg_F"]), int(g["cfg_batch"])
+    steps, every = int(g["cfg_steps"]), int(g["cfg_eval_every"])
+    ms = []
+    for seed in (11, 12):
+        m = NeRF()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
+        ms.append(m.to(dev))
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    rays, tgt = T(g["rays"], dev), T(g["target"], dev)
+    val_rays, val_tgt = T(g["val_rays"], dev), T(g["val_target"], dev)
+    opt = torch.optim.Adam([p for m in ms for p in m.parameters()], lr=float(g["cfg_lr"]), eps=1e-8)
+    psnr = []
+    for step in range(steps + 1):
+        if step % every == 0:
+            with torch.no_grad():
+                r = render_rays(ms, emb, val_rays, S, False, 0, 0, F, 1 << 15, True, False)
+            psnr.append(float(-10 * torch.log10(((r["rgb_fine"] - val_tgt) ** 2).mean())))
+        if step == steps:
+            break
+        idx = torch.from_numpy(synth.psnr_batch_indices(step, rays.shape[0], B)).to(dev)
+        rg = {k: T(v, dev) for k, v in synth.psnr_step_rng(step, B, S, F).items()}
+        res = render_rays(ms, emb, rays[idx], S, False, 1.0, 0.0, F, 1 << 15, True, False, rng=rg)
+        t = tgt[idx]
+        loss = ((res["rgb_coarse"] - t) ** 2).mean() + ((res["rgb_fine"] - t) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    ref = g["psnr"]
+    print("psnr hip", np.round(psnr, 3), "reference", np.round(ref, 3))
+    assert len(psnr) == len(ref)
+    assert abs(psnr[0] - ref[0]) < 0.01                     # untrained: identical models
+    assert np.abs(np.array(psnr) - ref).max() < 0.1, (psnr, ref)

@@ -41,12 +41,8 @@ def view_rays(res, view_seed):
     return np.concatenate([o, d, nf], -1).astype(np.float32)
 
 
-def step_rng(step, B, S, F):
-    return {"perturb_rand": synth.hash_uniform((B, S), 90000 + 4 * step), "u": synth.hash_uniform((B, F), 90001 + 4 * step)}
-
-
-def batch_indices(step, n_total, B):
-    return np.minimum((synth.hash_uniform((B,), 80000 + step) * n_total).astype(np.int64), n_total - 1)
+step_rng = synth.psnr_step_rng            # shared with tests/test_gpu_parity.py::test_psnr_parity
+batch_indices = synth.psnr_batch_indices
 
 
 def patched(rng_list):
