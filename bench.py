@@ -89,12 +89,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs for a 1-GPU box (never set by the driver): BENCH_BACKEND=gloo BENCH_SHARE_GPU=1 lets two
+    # ranks share cuda:0 and reduce through gloo, which exercises the same code path as RCCL
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    share = os.environ.get("BENCH_SHARE_GPU", "0") == "1"
+    dev_index = 0 if (world == 1 or share) else local_rank
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from nerf_siren_amd import Embedding, NeRF, render_rays, synth
     from nerf_siren_amd import ops

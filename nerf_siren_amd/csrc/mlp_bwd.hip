@@ -193,40 +193,76 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const bool is_a = (i * 256 + tid) < JB * 32 * 8;
+#ifdef DW_EXP_NOLOAD
+            stage[i] = ldg4(src[i] + t_lo * (is_a ? W_ROWS * 32 : SAVED_ROWS * 32));
+#else
             stage[i] = ldg4(src[i] + t * (is_a ? W_ROWS * 32 : SAVED_ROWS * 32));   // consumed one tile later
+#endif
         }
     };
-    if (t_lo < t_hi) load_tile(t_lo);
-    for (int64_t t = t_lo; t < t_hi; ++t) {
-        __syncthreads();                       // previous tile fully consumed
+    auto write_tile = [&](float *buf) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int u = i * 256 + tid, row = u >> 3, c4 = u & 7;
             // rows beyond the real operand (padding of the heads) are zeroed here, not at load time, so
             // that the loads stay in flight under the previous tile's MFMAs
-            *reinterpret_cast<f32x4 *>(lds + row * LROW + 4 * c4) = valid[i] ? stage[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(buf + row * LROW + 4 * c4) = valid[i] ? stage[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __syncthreads();
-        if (t + 1 < t_hi) load_tile(t + 1);    // in flight under the MFMAs below
+    };
+    // Double-buffered LDS, ONE barrier per tile: at the top of iteration t the registers hold tile t+1
+    // (loaded during iteration t-1); it is written into the other buffer (last read in iteration t-1, which
+    // every wave left through the barrier), tile t+2's loads are issued, then tile t is consumed.
+    float *buf0 = lds, *buf1 = lds + ROWS * LROW;
+    if (t_lo < t_hi) {
+        load_tile(t_lo);
+        write_tile(buf0);
+        if (t_lo + 1 < t_hi) load_tile(t_lo + 1);
+    }
+    __syncthreads();
+    for (int64_t t = t_lo; t < t_hi; ++t) {
+        const bool odd = ((t - t_lo) & 1) != 0;
+        const float *cur = odd ? buf1 : buf0;
+        float *nxt = odd ? buf0 : buf1;
+        // The staging work for the following tiles is spread over this tile's MFMA stream instead of sitting
+        // in front of it (a wave issues in order: a block of 16 ds_write_b128 + 16 global loads ahead of the
+        // first ds_read would leave the matrix pipe idle for ~3k cycles per tile): slot i of tile t+1 is written
+        // to the other LDS buffer, and its register reloaded for tile t+2, after MFMA group i*(groups/NLD).
+        // Past the end the (clamped) tile is staged redundantly, which keeps the loop branch-free.
+        const int64_t t2 = (t + 2 < t_hi) ? t + 2 : t_hi - 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 a[JW], b[KW];
 #pragma unroll
             for (int x = 0; x < JW; ++x)
-                a[x] = *reinterpret_cast<const f32x4 *>(lds + (32 * (wj * JW + x) + (lane & 31)) * LROW + 8 * q + 4 * half);
+                a[x] = *reinterpret_cast<const f32x4 *>(cur + (32 * (wj * JW + x) + (lane & 31)) * LROW + 8 * q + 4 * half);
 #pragma unroll
             for (int x = 0; x < KW; ++x)
-                b[x] = *reinterpret_cast<const f32x4 *>(lds + (32 * (JB + wk * KW + x) + (lane & 31)) * LROW + 8 * q + 4 * half);
+                b[x] = *reinterpret_cast<const f32x4 *>(cur + (32 * (JB + wk * KW + x) + (lane & 31)) * LROW + 8 * q + 4 * half);
 #pragma unroll
             for (int x = 0; x < JW; ++x) bsum[x] += (a[x][0] + a[x][1]) + (a[x][2] + a[x][3]);
 #pragma unroll
             for (int x = 0; x < JW; ++x)
 #pragma unroll
-                for (int y = 0; y < KW; ++y)
+                for (int y = 0; y < KW; ++y) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
                         acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x][s], b[y][s], acc[x][y], 0, 0, 0);
+                    // staging slots interleaved with the MFMA groups
+                    constexpr int NG = 4 * JW * KW;                       // MFMA groups per tile
+                    const int gidx = (q * JW + x) * KW + y;
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i) {
+                        if (gidx == (i * NG) / NLD) {
+                            const int u = i * 256 + tid, row = u >> 3, c4 = u & 7;
+                            *reinterpret_cast<f32x4 *>(nxt + row * LROW + 4 * c4) =
+                                valid[i] ? stage[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                            const bool is_a = (i * 256 + tid) < JB * 32 * 8;
+                            stage[i] = ldg4(src[i] + t2 * (is_a ? W_ROWS * 32 : SAVED_ROWS * 32));
+                        }
+                    }
+                }
         }
+        __syncthreads();
     }
     // partial slab [chunk][32*JB][32*KB] then bias slab [chunk][32*JB]
     float *slab = partial + T.part_off + (int64_t)chunk * (JB * 32 * (KB * 32 + 1));
@@ -372,7 +408,7 @@ int nerfmi_nerf_backward_rays(const float *packed, const float *rays, const floa
     hipLaunchKernelGGL(nerf_backward_chain_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
                        grad_out, n_points, ld, work);
     const DwPlan P = make_plan(ld);
-    const size_t lds = sizeof(float) * 512 * LROW;      // 73 728 B > the 64 KiB default dynamic-LDS limit
+    const size_t lds = sizeof(float) * 2 * 512 * LROW;  // two 73 728-B tile buffers (> the 64 KiB default dynamic-LDS limit)
     static thread_local bool lds_attr_set = false;
     if (!lds_attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
