@@ -192,16 +192,45 @@ int nerfmi_eg3d_march(const float *colors, const float *densities, const float *
 /* sample_importance (renderer.py:197-256): depths (R,S), weights (R,S-1), u (R,F) = the torch.rand draw -> z_out (R,F). */
 int nerfmi_eg3d_sample_importance(const float *depths, const float *weights, const float *u, int64_t n_rays,
                                   int n_samples, int n_importance, float *z_out, nerfmi_stream_t stream);
-/* unify_samples (renderer.py:160-170): sort by depth and gather colours (.,3) and densities. */
+/* unify_samples (renderer.py:160-170): sort by depth and gather colours (.,3) and densities.
+ * idx_out (R, n1+n2) int32, optional: source position of every sorted sample (for the backward). */
 int nerfmi_eg3d_unify(const float *d1, const float *c1, const float *s1, const float *d2, const float *c2,
                       const float *s2, int64_t n_rays, int n1, int n2, float *d_out, float *c_out, float *s_out,
-                      nerfmi_stream_t stream);
+                      int32_t *idx_out, nerfmi_stream_t stream);
 /* RaySampler.forward (ray_sampler.py:24-63): cam2world (n,4,4), intrinsics (n,3,3) -> origins/dirs (n, res*res, 3). */
 int nerfmi_eg3d_ray_sampler(const float *cam2world, const float *intrinsics, int n, int resolution, float *origins_out,
                             float *dirs_out, nerfmi_stream_t stream);
 /* get_ray_limits_box (math_utils.py:46-98): (n,3),(n,3) -> tmin (n), tmax (n); misses = (-1,-2). */
 int nerfmi_eg3d_ray_limits_box(const float *rays_o, const float *rays_d, int64_t n, float box_side_length,
                                float *tmin_out, float *tmax_out, nerfmi_stream_t stream);
+
+/* ---- EG3D backward: the autograd graph of renderer.py:88-142 w.r.t. planes and OSGDecoder parameters ----
+ * (depths carry no gradient: stratified draws, and sample_importance runs under no_grad, renderer.py:201) */
+/* d(colors, densities) of MipRayMarcher2.run_forward given d(rgb, depth, weights.sum); accumulate != 0 adds
+ * into d_colors / d_densities (coarse samples also receive gradient through the fine march). */
+int nerfmi_eg3d_march_backward(const float *colors, const float *densities, const float *depths, const float *minmax,
+                               const float *g_rgb, const float *g_depth, const float *g_weight_sum, int64_t n_rays,
+                               int n_samples, int white_back, int accumulate, float *d_colors, float *d_densities,
+                               nerfmi_stream_t stream);
+/* inverse of nerfmi_eg3d_unify's permutation. */
+int nerfmi_eg3d_unify_backward(const int32_t *idx, const float *g_colors, const float *g_densities, int64_t n_rays,
+                               int n1, int n2, float *d_c1, float *d_s1, float *d_c2, float *d_s2,
+                               nerfmi_stream_t stream);
+/* backward of nerfmi_eg3d_run_model_rays: d_rgb (n, M*S, 3), d_sigma (n, M*S) -> float-atomic scatter-add into
+ * gplanes_hwc (n*3, H, W, 32; caller zero-fills) and a per-point scratch image `aux`
+ * (nerfmi_eg3d_backward_aux_floats(n*M*S) floats) consumed by nerfmi_eg3d_decoder_wgrad. */
+size_t nerfmi_eg3d_backward_aux_floats(int64_t n_points);
+int nerfmi_eg3d_run_model_rays_backward(const float *planes_hwc, int n, int h, int w, const float *decoder_packed,
+                                        const float *ray_origins, const float *ray_directions, const float *depths,
+                                        int64_t n_rays_per_batch, int n_samples, float box_warp, const float *d_rgb,
+                                        const float *d_sigma, float *gplanes_hwc, float *aux, nerfmi_stream_t stream);
+/* decoder parameter gradients from `aux` (deterministic chunk slabs; partial: nerfmi_eg3d_wgrad_partial_floats()). */
+size_t nerfmi_eg3d_wgrad_partial_floats(void);
+int nerfmi_eg3d_decoder_wgrad(const float *aux, int64_t n_points, float lr_multiplier, int accumulate, float *partial,
+                              float *g_w0, float *g_b0, float *g_w1, float *g_b1, nerfmi_stream_t stream);
+/* channels-last (n_planes,H,W,C) -> (n_planes,C,H,W): the plane gradient in the reference's layout. */
+int nerfmi_eg3d_unpack_planes(const float *planes_hwc, int n_planes, int channels, int h, int w, float *planes_nchw,
+                              nerfmi_stream_t stream);
 
 #ifdef __cplusplus
 }

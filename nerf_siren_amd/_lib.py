@@ -41,7 +41,14 @@ SIGNATURES = {
     "nerfmi_eg3d_minmax": (_i, [_f, _i64, _f, _f]),
     "nerfmi_eg3d_march": (_i, [_f, _f, _f, _f, _i64, _i, _i, _f, _f, _f, _f, _f]),
     "nerfmi_eg3d_sample_importance": (_i, [_f, _f, _f, _i64, _i, _i, _f, _f]),
-    "nerfmi_eg3d_unify": (_i, [_f, _f, _f, _f, _f, _f, _i64, _i, _i, _f, _f, _f, _f]),
+    "nerfmi_eg3d_unify": (_i, [_f, _f, _f, _f, _f, _f, _i64, _i, _i, _f, _f, _f, _f, _f]),
+    "nerfmi_eg3d_march_backward": (_i, [_f, _f, _f, _f, _f, _f, _f, _i64, _i, _i, _i, _f, _f, _f]),
+    "nerfmi_eg3d_unify_backward": (_i, [_f, _f, _f, _i64, _i, _i, _f, _f, _f, _f, _f]),
+    "nerfmi_eg3d_backward_aux_floats": (C.c_size_t, [_i64]),
+    "nerfmi_eg3d_run_model_rays_backward": (_i, [_f, _i, _i, _i, _f, _f, _f, _f, _i64, _i, _fl, _f, _f, _f, _f, _f]),
+    "nerfmi_eg3d_wgrad_partial_floats": (C.c_size_t, []),
+    "nerfmi_eg3d_decoder_wgrad": (_i, [_f, _i64, _fl, _i, _f, _f, _f, _f, _f, _f]),
+    "nerfmi_eg3d_unpack_planes": (_i, [_f, _i, _i, _i, _i, _f, _f]),
     "nerfmi_eg3d_ray_sampler": (_i, [_f, _f, _i, _i, _f, _f, _f]),
     "nerfmi_eg3d_ray_limits_box": (_i, [_f, _f, _i64, _fl, _f, _f, _f]),
     "nerfmi_composite": (_i, [_f, _i, _f, _f, _f, _fl, _i, _i, _i, _f, _f, _f, _f, _f]),

@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(64)
 eg3d_unify_kernel(const float *__restrict__ d1, const float *__restrict__ c1, const float *__restrict__ s1,
                   const float *__restrict__ d2, const float *__restrict__ c2, const float *__restrict__ s2, int64_t R,
                   int S, int F, int npad, float *__restrict__ d_out, float *__restrict__ c_out,
-                  float *__restrict__ s_out) {
+                  float *__restrict__ s_out, int *__restrict__ idx_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *key = lds;
     int *idx = reinterpret_cast<int *>(lds + npad);
@@ -376,6 +376,7 @@ eg3d_unify_kernel(const float *__restrict__ d1, const float *__restrict__ c1, co
             }
         for (int k = lane; k < n; k += WAVE) {
             const int src = idx[k];
+            if (idx_out) idx_out[r * n + k] = src;      // the permutation, kept for the backward
             d_out[r * n + k] = key[k];
             const float *cs = src < S ? c1 + (r * S + src) * 3 : c2 + (r * F + (src - S)) * 3;
             c_out[(r * n + k) * 3 + 0] = cs[0];
@@ -570,14 +571,14 @@ int nerfmi_eg3d_sample_importance(const float *depths, const float *weights, con
 
 int nerfmi_eg3d_unify(const float *d1, const float *c1, const float *s1, const float *d2, const float *c2,
                       const float *s2, int64_t n_rays, int n1, int n2, float *d_out, float *c_out, float *s_out,
-                      nerfmi_stream_t stream) {
+                      int32_t *idx_out, nerfmi_stream_t stream) {
     NERFMI_REQUIRE(n_rays >= 0 && n1 >= 1 && n2 >= 0 && n1 + n2 <= 8192, "eg3d_unify: bad sizes");
     if (n_rays == 0) return NERFMI_OK;
     NERFMI_REQUIRE(d1 && c1 && s1 && (n2 == 0 || (d2 && c2 && s2)) && d_out && c_out && s_out, "eg3d_unify: null pointer");
     const int npad = next_pow2(n1 + n2 < 2 ? 2 : n1 + n2);
     hipLaunchKernelGGL(eg3d_unify_kernel, dim3((unsigned)(n_rays < 65536 ? n_rays : 65536)), dim3(64),
                        sizeof(float) * 2 * npad, (hipStream_t)stream, d1, c1, s1, d2, c2, s2, n_rays, n1, n2, npad, d_out,
-                       c_out, s_out);
+                       c_out, s_out, (int *)idx_out);
     return check_launch("eg3d_unify");
 }
 

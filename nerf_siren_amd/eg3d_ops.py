@@ -114,7 +114,7 @@ def sample_importance(depths, weights, u):
     return out
 
 
-def unify(d1, c1, s1, d2, c2, s2):
+def unify(d1, c1, s1, d2, c2, s2, want_idx=False):
     d1 = _req(d1, "depths1", (None, None))
     r, n1 = d1.shape
     d2 = _req(d2.reshape(r, -1), "depths2")
@@ -125,9 +125,67 @@ def unify(d1, c1, s1, d2, c2, s2):
     d = torch.empty((r, n1 + n2), device=dev, dtype=torch.float32)
     c = torch.empty((r, n1 + n2, 3), device=dev, dtype=torch.float32)
     s = torch.empty((r, n1 + n2), device=dev, dtype=torch.float32)
+    idx = torch.empty((r, n1 + n2), device=dev, dtype=torch.int32) if want_idx else None
     check(_lib.lib().nerfmi_eg3d_unify(ptr(d1), ptr(c1), ptr(s1), ptr(d2), ptr(c2), ptr(s2), r, n1, n2, ptr(d), ptr(c),
-                                       ptr(s), _stream(d1)), "eg3d_unify")
-    return d, c, s
+                                       ptr(s), ptr(idx), _stream(d1)), "eg3d_unify")
+    return (d, c, s, idx) if want_idx else (d, c, s)
+
+
+def march_backward(colors, densities, depths, mm, g_rgb, g_depth, g_wsum, white_back, into=None):
+    """-> d_colors (R,S,3), d_densities (R,S); `into` = (d_colors, d_densities) to accumulate into."""
+    r, s = colors.shape[0], colors.shape[1]
+    dev = colors.device
+    acc = into is not None
+    dc, ds = into if acc else (torch.empty((r, s, 3), device=dev, dtype=torch.float32),
+                               torch.empty((r, s), device=dev, dtype=torch.float32))
+    g_rgb = _req(g_rgb.reshape(r, 3), "g_rgb") if g_rgb is not None else None
+    g_depth = _req(g_depth.reshape(r), "g_depth") if g_depth is not None else None
+    g_wsum = _req(g_wsum.reshape(r), "g_wsum") if g_wsum is not None else None
+    check(_lib.lib().nerfmi_eg3d_march_backward(ptr(colors), ptr(densities), ptr(depths), ptr(mm), ptr(g_rgb),
+                                                ptr(g_depth), ptr(g_wsum), r, s, int(bool(white_back)), int(acc),
+                                                ptr(dc), ptr(ds), _stream(colors)), "eg3d_march_backward")
+    return dc, ds
+
+
+def unify_backward(idx, g_c, g_s, n1, n2):
+    r = idx.shape[0]
+    dev = idx.device
+    dc1 = torch.empty((r, n1, 3), device=dev, dtype=torch.float32)
+    ds1 = torch.empty((r, n1), device=dev, dtype=torch.float32)
+    dc2 = torch.empty((r, n2, 3), device=dev, dtype=torch.float32)
+    ds2 = torch.empty((r, n2), device=dev, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_unify_backward(ptr(idx), ptr(g_c), ptr(g_s), r, n1, n2, ptr(dc1), ptr(ds1), ptr(dc2),
+                                                ptr(ds2), _stream(idx)), "eg3d_unify_backward")
+    return dc1, ds1, dc2, ds2
+
+
+def run_model_rays_backward(planes_hwc, n, dec, ray_o, ray_d, depths, box_warp, d_rgb, d_sigma, gplanes_hwc):
+    m = ray_o.shape[1]
+    depths = depths.reshape(n, m, -1)
+    s = depths.shape[2]
+    h, w = planes_hwc.shape[1], planes_hwc.shape[2]
+    npts = n * m * s
+    aux = torch.empty(_lib.lib().nerfmi_eg3d_backward_aux_floats(npts), device=ray_o.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_run_model_rays_backward(ptr(planes_hwc), n, h, w, ptr(dec), ptr(ray_o), ptr(ray_d),
+                                                         ptr(depths), m, s, float(box_warp),
+                                                         ptr(_req(d_rgb.reshape(npts, 3), "d_rgb")),
+                                                         ptr(_req(d_sigma.reshape(npts), "d_sigma")), ptr(gplanes_hwc),
+                                                         ptr(aux), _stream(ray_o)), "eg3d_run_model_rays_backward")
+    return aux, npts
+
+
+def decoder_wgrad(aux, npts, lr_mul, grads, accumulate):
+    partial = torch.empty(_lib.lib().nerfmi_eg3d_wgrad_partial_floats(), device=aux.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_decoder_wgrad(ptr(aux), npts, float(lr_mul), int(bool(accumulate)), ptr(partial),
+                                               ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]), _stream(aux)),
+          "eg3d_decoder_wgrad")
+
+
+def unpack_planes(g_hwc, n):
+    _, h, w, c = g_hwc.shape
+    out = torch.empty((n, 3, c, h, w), device=g_hwc.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_eg3d_unpack_planes(ptr(g_hwc), n * 3, c, h, w, ptr(out), _stream(g_hwc)), "eg3d_unpack_planes")
+    return out
 
 
 def ray_sampler(cam2world, intrinsics, resolution):

@@ -1,7 +1,8 @@
 """volumetric_rendering/renderer.py:23-256 (ImportanceRenderer and helpers) on the gfx950 kernels.
 
-Forward only this round: the reference's backward (grads to planes / decoder) is not implemented, so the
-renderer raises if called with grad-requiring inputs while grad is enabled.
+Training: when grad is enabled and the planes or the decoder require grad, the whole forward is ONE autograd
+node (`_RenderFn`) whose backward is marcher(fine) -> unify^-1 -> marcher(coarse) -> decoder/tri-plane scatter
+(csrc/eg3d_bwd.hip); depths carry no gradient, as in the reference (renderer.py:201 no_grad).
 rendering_options may carry two extra keys to inject the reference's random draws (parity tests):
 'rng_stratified' (N,M,S,1) = the rand_like of sample_stratified, 'rng_importance' (N*M,F) = the rand of sample_pdf.
 """
@@ -35,6 +36,55 @@ def sample_from_planes(plane_axes, plane_features, coordinates, mode='bilinear',
     return eg3d_ops.sample_planes(eg3d_ops.pack_planes(plane_features), n, coordinates, box_warp)
 
 
+class _RenderFn(torch.autograd.Function):
+    """ImportanceRenderer.forward (fixed or 'auto' ray limits resolved by the caller) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, ren, decoder, opts, depths_coarse, u, ray_o, ray_d, planes, w0, b0, w1, b1):
+        N, M, _ = ray_o.shape
+        S = depths_coarse.shape[1]
+        F = u.shape[1]
+        wb = opts.get('white_back', False)
+        planes_hwc = ren._pack(planes)
+        dec = decoder.packed()
+        colors_c, dens_c = eg3d_ops.run_model_rays(planes_hwc, N, dec, ray_o, ray_d, depths_coarse, opts['box_warp'])
+        cc, sc = colors_c.reshape(N * M, S, 3), dens_c.reshape(N * M, S)
+        mm_c = eg3d_ops.minmax(depths_coarse)
+        rgb_c, depth_c, w_c, wsum_c = eg3d_ops.march(cc, sc, depths_coarse, wb, mm_c)
+        depths_fine = eg3d_ops.sample_importance(depths_coarse, w_c, u)
+        colors_f, dens_f = eg3d_ops.run_model_rays(planes_hwc, N, dec, ray_o, ray_d, depths_fine, opts['box_warp'])
+        cf, sf = colors_f.reshape(N * M, F, 3), dens_f.reshape(N * M, F)
+        all_d, all_c, all_s, idx = eg3d_ops.unify(depths_coarse, cc, sc, depths_fine, cf, sf, want_idx=True)
+        mm_f = eg3d_ops.minmax(all_d)
+        rgb_f, depth_f, _, wsum_f = eg3d_ops.march(all_c, all_s, all_d, wb, mm_f)
+        ctx.save_for_backward(planes_hwc, dec, ray_o, ray_d, depths_coarse, depths_fine, cc, sc, all_d, all_c, all_s, idx,
+                              mm_c, mm_f)
+        ctx.cfg = (N, M, S, F, bool(wb), float(opts['box_warp']), float(decoder.lr_mul), tuple(planes.shape))
+        v = lambda t, c: t.view(N, M, c)
+        return v(rgb_c, 3), v(depth_c, 1), v(wsum_c, 1), v(rgb_f, 3), v(depth_f, 1), v(wsum_f, 1)
+
+    @staticmethod
+    def backward(ctx, g_rgb_c, g_depth_c, g_w_c, g_rgb_f, g_depth_f, g_w_f):
+        (planes_hwc, dec, ray_o, ray_d, depths_c, depths_f, cc, sc, all_d, all_c, all_s, idx, mm_c, mm_f) = ctx.saved_tensors
+        N, M, S, F, wb, box_warp, lr_mul, pshape = ctx.cfg
+        z = lambda g: None if g is None else g.contiguous()
+        # fine march -> inverse permutation -> coarse march (accumulating into the coarse slots)
+        d_all_c, d_all_s = eg3d_ops.march_backward(all_c, all_s, all_d, mm_f, z(g_rgb_f), z(g_depth_f), z(g_w_f), wb)
+        d_cc, d_sc, d_cf, d_sf = eg3d_ops.unify_backward(idx, d_all_c, d_all_s, S, F)
+        eg3d_ops.march_backward(cc, sc, depths_c, mm_c, z(g_rgb_c), z(g_depth_c), z(g_w_c), wb, into=(d_cc, d_sc))
+        gplanes_hwc = torch.zeros_like(planes_hwc)
+        grads = [torch.empty(64, 32, device=dec.device), torch.empty(64, device=dec.device),
+                 torch.empty(4, 64, device=dec.device), torch.empty(4, device=dec.device)]
+        aux, npts = eg3d_ops.run_model_rays_backward(planes_hwc, N, dec, ray_o, ray_d, depths_c, box_warp, d_cc, d_sc,
+                                                     gplanes_hwc)
+        eg3d_ops.decoder_wgrad(aux, npts, lr_mul, grads, accumulate=False)
+        aux, npts = eg3d_ops.run_model_rays_backward(planes_hwc, N, dec, ray_o, ray_d, depths_f, box_warp, d_cf, d_sf,
+                                                     gplanes_hwc)
+        eg3d_ops.decoder_wgrad(aux, npts, lr_mul, grads, accumulate=True)
+        g_planes = eg3d_ops.unpack_planes(gplanes_hwc, N).view(pshape)
+        return (None, None, None, None, None, None, None, g_planes, *grads)
+
+
 class ImportanceRenderer(torch.nn.Module):
     def __init__(self):
         super().__init__()
@@ -53,9 +103,7 @@ class ImportanceRenderer(torch.nn.Module):
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
         """-> rgb_coarse (N,M,3), depth_coarse (N,M,1), weights_coarse.sum(2) (N,M,1), rgb_final, depth_final,
         weights.sum(2)  (renderer.py:88-142)."""
-        if torch.is_grad_enabled() and (planes.requires_grad or any(p.requires_grad for p in decoder.parameters())):
-            raise NotImplementedError("ImportanceRenderer backward (grads to planes/decoder) is not implemented yet; "
-                                      "call under torch.no_grad()")
+        train = torch.is_grad_enabled() and (planes.requires_grad or any(p.requires_grad for p in decoder.parameters()))
         opts = rendering_options
         N, M, _ = ray_origins.shape
         S = opts['depth_resolution']
@@ -72,10 +120,21 @@ class ImportanceRenderer(torch.nn.Module):
         else:
             depths_coarse = eg3d_ops.sample_stratified(N * M, S, rs, opts['ray_start'], opts['ray_end'],
                                                        opts.get('disparity_space_sampling', False))
+        o, d = ray_origins.detach().contiguous(), ray_directions.detach().contiguous()
+        if train:
+            if opts.get('density_noise', 0) > 0:
+                raise NotImplementedError("density_noise is not supported in training mode")
+            F_ = opts['depth_resolution_importance']
+            if F_ <= 0:
+                raise SystemExit
+            u_ = opts.get('rng_importance')
+            u_ = torch.rand((N * M, F_), device=dev) if u_ is None else u_.reshape(N * M, F_)
+            net = decoder.net
+            return _RenderFn.apply(self, decoder, opts, depths_coarse, u_.contiguous(), o, d, planes, net[0].weight,
+                                   net[0].bias, net[2].weight, net[2].bias)
         planes_hwc = self._pack(planes)
         dec = decoder.packed()
         wb = opts.get('white_back', False)
-        o, d = ray_origins.contiguous(), ray_directions.contiguous()
 
         colors_coarse, dens_coarse = eg3d_ops.run_model_rays(planes_hwc, N, dec, o, d, depths_coarse, opts['box_warp'])
         if opts.get('density_noise', 0) > 0:                                     # renderer.py:149-150

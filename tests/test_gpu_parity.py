@@ -544,9 +544,37 @@ def test_eg3d_forward(golden, dev, osg):
             assert (err <= tol).mean() >= 0.9 and err.max() <= 100 * tol, (k, err.max())
             if k.endswith("_c"):
                 assert err.max() <= tol, (k, err.max())
-    planes.requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        ImportanceRenderer()(planes, osg, T(g["ray_o"][None], dev), T(g["ray_d"][None], dev), opts)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_eg3d_backward(golden, dev, osg, tag):
+    """loss.backward() through ImportanceRenderer: gradients w.r.t. planes and OSGDecoder parameters against
+    the reference's autograd (tools/make_golden.py g_eg3d_grad)."""
+    from nerf_siren_amd import ImportanceRenderer
+    g = golden("g16_eg3d_grad_" + tag)
+    res_ = int(g["res"])
+    planes = T(synth.triplanes(8, res=res_), dev).requires_grad_(True)
+    for p in osg.parameters():
+        p.grad = None
+    opts = dict(synth.EG3D_OPTIONS, white_back=bool(g["white_back"]), rng_stratified=T(g["rand_strat"], dev),
+                rng_importance=T(g["u"], dev))
+    res = ImportanceRenderer()(planes, osg, T(g["ray_o"][None], dev), T(g["ray_d"][None], dev), opts)
+    t = T(g["target"], dev)
+    loss = ((res[0] - t) ** 2).mean() + ((res[3] - t) ** 2).mean() + 0.05 * res[1].mean() + 0.02 * (res[4] ** 2).mean() \
+        + 0.3 * res[2].mean() - 0.2 * res[5].mean()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-4
+    loss.backward()
+    gp = N(planes.grad)
+    assert gp.shape == (1, 3, 32, res_, res_)
+    ref_sub = g["gplanes_sub"]
+    mine_sub = gp.reshape(-1)[::7]
+    rel = np.linalg.norm(mine_sub.astype(np.float64) - ref_sub) / (np.linalg.norm(ref_sub.astype(np.float64)) + 1e-12)
+    assert rel < 2e-2, rel              # fine samples inherit sample_pdf's conditioning (see the NeRF gradient tests)
+    assert abs(np.linalg.norm(gp.astype(np.float64)) - float(g["gplanes_norm"])) < 2e-2 * float(g["gplanes_norm"])
+    for k, p in osg.named_parameters():
+        ref = g["gdec_" + k]
+        err = np.linalg.norm(N(p.grad).astype(np.float64) - ref) / (np.linalg.norm(ref.astype(np.float64)) + 1e-12)
+        assert err < 2e-2, (k, err)
 
 
 @pytest.mark.parametrize("res", [2, 8])

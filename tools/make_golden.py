@@ -408,12 +408,55 @@ def g_eg3d():
     save("g14_eg3d_box", ray_o=ro, ray_d=rd, tmin=tmin, tmax=tmax)
 
 
+def g_eg3d_grad():
+    """G16: ImportanceRenderer forward + loss.backward(): reference autograd gradients w.r.t. the planes and
+    the OSGDecoder parameters (the EG3D training path, system.py:17-169 -> eg3d_renderer.render)."""
+    from volumetric_rendering.renderer import ImportanceRenderer
+    from eg3d_training.triplane import OSGDecoder
+    dec = OSGDecoder(32, {"decoder_lr_mul": 1.0, "decoder_output_dim": 3})
+    dec.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.osg_params(4).items()})
+    ren = ImportanceRenderer()
+    for tag, wb, res_ in (("a", False, 32), ("b", True, 16)):
+        opts = dict(synth.EG3D_OPTIONS, white_back=wb)
+        planes = torch.from_numpy(synth.triplanes(8, res=res_)).requires_grad_(True)
+        M = 40
+        o, d = synth.eg3d_rays(M, 71)
+        rs = synth.hash_uniform((1, M, 64, 1), 730)
+        u2 = synth.hash_uniform((M, 64), 731)
+        tgt = synth.hash_uniform((1, M, 3), 732)
+        _rand, _rl = torch.rand, torch.rand_like
+        torch.rand = lambda *a, **k: torch.from_numpy(u2.copy())
+        torch.rand_like = lambda t, **k: torch.from_numpy(rs.copy())
+        try:
+            res = ren(planes, dec, torch.from_numpy(o[None]), torch.from_numpy(d[None]), opts)
+        finally:
+            torch.rand, torch.rand_like = _rand, _rl
+        t = torch.from_numpy(tgt)
+        loss = ((res[0] - t) ** 2).mean() + ((res[3] - t) ** 2).mean() + 0.05 * res[1].mean() + 0.02 * (res[4] ** 2).mean() \
+            + 0.3 * res[2].mean() - 0.2 * res[5].mean()
+        for p in dec.parameters():
+            p.grad = None
+        loss.backward()
+        gp = planes.grad.numpy()
+        out = dict(ray_o=o, ray_d=d, rand_strat=rs, u=u2, target=tgt, white_back=wb, res=res_, loss=loss.detach(),
+                   gplanes_sub=gp.reshape(-1)[::7].copy(), gplanes_norm=np.linalg.norm(gp.astype(np.float64)),
+                   gplanes_nnz=(gp != 0).sum())
+        for k, p in dec.named_parameters():
+            out["gdec_" + k] = p.grad.clone()
+        for i, nm in enumerate(("rgb_c", "depth_c", "op_c", "rgb_f", "depth_f", "op_f")):
+            out[nm] = res[i].detach()
+        save("g16_eg3d_grad_" + tag, **out)
+
+
 def main():
+    if "--only-eg3d-grad" in sys.argv:
+        return g_eg3d_grad()
     if "--only-siren" in sys.argv:
         return g_siren()
     if "--only-eg3d" in sys.argv:
         return g_eg3d()
     g_eg3d()
+    g_eg3d_grad()
     g_siren()
     g_primitives()
     g_composite()
