@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="rays per rank per step (configs[1])")
     ap.add_argument("--field", choices=["nerf", "siren"], default="nerf",
                     help="nerf = the reference's live 8x256 ReLU NeRF; siren = its FiLM-SIREN field (inference only)")
+    ap.add_argument("--math", choices=["fp32", "bf16x3"], default="fp32",
+                    help="fp32 = exact fp32 MFMA (default); bf16x3 = opt-in split-bf16 inference math (--mode infer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work in the bounded cpu_baseline sample")
     return ap.parse_args()
@@ -108,6 +110,11 @@ def main():
     from nerf_siren_amd.parallel import FlatGradAllReduce
 
     B = args.batch
+    if args.math != "fp32":
+        if args.mode != "infer" or args.field != "nerf":
+            raise SystemExit("--math bf16x3 applies to --mode infer --field nerf")
+        import nerf_siren_amd
+        nerf_siren_amd.set_math(args.math)
     models = []
     siren = args.field == "siren"
     if siren and args.mode != "infer":
@@ -151,6 +158,20 @@ def main():
 
     import nerf_siren_amd.rendering as R
     R.ops.nerf_forward_rays = timed_fwd
+    if args.math == "bf16x3":
+        orig_fast = ops.nerf_forward_rays_fast
+
+        def timed_fast(packed, fast, rays, z, sigma_only=False):
+            if z.shape[1] != 128:
+                return orig_fast(packed, fast, rays, z, sigma_only)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = orig_fast(packed, fast, rays, z, sigma_only)
+            b.record()
+            ev.append((a, b))
+            return out
+
+        ops.nerf_forward_rays_fast = timed_fast
     if siren:
         orig_siren = ops.siren_forward_rays
 
@@ -214,6 +235,8 @@ def main():
         pass
     flops_per_launch = B * 128 * (FLOP_SIREN if siren else FLOP_FULL)
     achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
+    # exact fp32 MFMA: 157.3 TF dense; split-bf16 (six bf16 MFMAs per fp32-equivalent product): 2500/6
+    peak = PEAK_F32_MFMA if args.math == "fp32" else 2500.0 / 6.0
 
     if rank == 0:
         total_samples = world * B * 192 * args.steps
@@ -222,16 +245,18 @@ def main():
                       + (" (training step)" if train else " (inference, test_time)"),
             "value": total_samples / dt, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.math == "fp32" else "f32 (3xbf16 split, 6 bf16 MFMA per product)", "data": "synthetic",
             "config": {"workload": f"configs[1]: Blender-lego 400x400 rays, N_samples=64 N_importance=64, "
                                    f"batch_size={B} rays/GPU, {'FiLM-SIREN 9x256' if siren else 'NeRF 8x256'} coarse+fine, "
                                    f"mode={args.mode}",
                        "rays_per_gpu": B, "samples_per_ray": 192, "mode": args.mode,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "rays_per_s": world * B * args.steps / dt,
-            "roofline": {"bound": "mfma", "kernel": ("siren_forward_kernel" if siren else "nerf_forward_kernel") + " (fine MLP, 128 samples/ray)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": ("siren_forward_kernel" if siren else ("nerf_forward_kernel" if args.math == "fp32" else
+                                                                          "nerf_forward_bf16x3_kernel"))
+                                   + " (fine MLP, 128 samples/ray)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": kern_ms},
         }
         if world == 1 and not args.no_cpu_baseline and not siren:

@@ -9,7 +9,7 @@ __version__ = "0.1.0"
 
 def __getattr__(name):
     # torch-dependent modules load lazily so that `nerf_siren_amd.synth` stays numpy-only
-    if name in ("render_rays", "sample_pdf"):
+    if name in ("render_rays", "sample_pdf", "set_math", "get_math"):
         from . import rendering
         return getattr(rendering, name)
     if name in ("Embedding", "NeRF", "SemanticNeRF", "FiLMLayer", "SirenField"):

@@ -117,7 +117,10 @@ __device__ __forceinline__ void layer_mfma(const float *__restrict__ wp, const f
 // slots make one barrier per stage sufficient (slot (s+1)%3 was last read in stage s-2, which every wave
 // finished before the previous barrier).
 // ---------------------------------------------------------------------------------------------------
-constexpr int GS = 16;                     // fragments (1 KiB each) per stage
+#ifndef NERFMI_GS
+#define NERFMI_GS 16
+#endif
+constexpr int GS = NERFMI_GS;              // fragments (1 KiB each) per stage
 constexpr int NSLOT = 3;
 constexpr int WLDS_FLOATS = NSLOT * GS * 256;   // 48 KiB
 
@@ -127,19 +130,20 @@ __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, 
                                                float *wlds, int wid, int lane) {
     constexpr int KBT = KB0 + KB1;
     constexpr int G = JB * KBT * 4;
-    static_assert(G % GS == 0, "layer image must be a whole number of stages");
-    constexpr int NST = G / GS;
-    const float *gsrc = wbase + (4 * wid) * 256 + lane * 4;        // this wave's quarter of every stage
-    float *ldst = wlds + (4 * wid) * 256 + lane * 4;
+    constexpr int NST = (G + GS - 1) / GS;                          // the last stage may be partial
+    constexpr int QS = GS / 4;                                      // fragments per wave per stage
+    const float *gsrc = wbase + (QS * wid) * 256 + lane * 4;        // this wave's quarter of every stage
+    float *ldst = wlds + (QS * wid) * 256 + lane * 4;
     const float *lsrc = wlds + lane * 4;
-    f32x4 st[4];
+    f32x4 st[QS];
     auto gload = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) st[i] = ldg4(gsrc + (stage * GS + i) * 256);
+        for (int i = 0; i < QS; ++i)
+            if ((stage + 1) * GS <= G || stage * GS + QS * wid + i < G) st[i] = ldg4(gsrc + (stage * GS + i) * 256);
     };
     auto lwrite = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(ldst + ((stage % NSLOT) * GS + i) * 256) = st[i];
+        for (int i = 0; i < QS; ++i) *reinterpret_cast<f32x4 *>(ldst + ((stage % NSLOT) * GS + i) * 256) = st[i];
     };
     __syncthreads();                       // every wave is done reading the previous layer's slots
     gload(0);

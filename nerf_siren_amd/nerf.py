@@ -58,6 +58,7 @@ class NeRF(nn.Module):
         self.rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
         self._packed = None
         self._packed_key = None
+        self._fast = None
 
     # -- parameters in C-ABI order -------------------------------------------------
     def param_list(self):
@@ -74,6 +75,14 @@ class NeRF(nn.Module):
                                                                and self._packed.device == ps[0].device) else None)
             self._packed_key = key
         return self._packed
+
+    def packed_fast(self):
+        """bf16x3 split image for the opt-in fast inference math (rendering.set_math('bf16x3'))."""
+        pk = self.packed()
+        if getattr(self, "_fast_key", None) is not self._packed_key or self._fast is None:
+            self._fast = ops.nerf_pack_fast(pk)
+            self._fast_key = self._packed_key
+        return self._fast
 
     def forward(self, x, sigma_only=False):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

@@ -122,6 +122,24 @@ def nerf_forward_rays(packed, rays, z, sigma_only=False, save=False):
     return (out, saved) if save else out
 
 
+def nerf_pack_fast(packed):
+    """bf16x3 split image of the forward weights (csrc/mlp_bf16x3.hip)."""
+    out = torch.empty(_lib.lib().nerfmi_nerf_fast_bytes(), device=packed.device, dtype=torch.uint8)
+    check(_lib.lib().nerfmi_nerf_pack_fast(ptr(packed), ptr(out), _stream(packed)), "nerf_pack_fast")
+    return out
+
+
+def nerf_forward_rays_fast(packed, fast, rays, z, sigma_only=False):
+    rays = _req(rays, "rays", (None, 8))
+    z = _req(z, "z", (rays.shape[0], None))
+    n, p = z.shape
+    out = torch.empty((n * p, 1 if sigma_only else 4), device=rays.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_nerf_forward_rays_fast(ptr(packed), ptr(fast), ptr(rays), ptr(z), n, p,
+                                                   int(bool(sigma_only)), ptr(out), _stream(rays)),
+          "nerf_forward_rays_fast")
+    return out
+
+
 def nerf_forward_embedded(packed, x, sigma_only=False):
     x = _req(x, "x", (None, 63 if sigma_only else 90))
     packed = _req(packed, "packed", (_lib.lib().nerfmi_nerf_packed_floats(),))

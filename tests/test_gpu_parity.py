@@ -643,3 +643,39 @@ def test_psnr_parity(golden, dev):
     assert len(psnr) == len(ref)
     assert abs(psnr[0] - ref[0]) < 0.01                     # untrained: identical models
     assert np.abs(np.array(psnr) - ref).max() < 0.1, (psnr, ref)
+
+
+# --------------------------------------------------------------------------- opt-in bf16x3 math
+@pytest.mark.parametrize("n_rays,P", [(5, 64), (3, 128), (7, 24), (33, 64)])
+def test_nerf_mlp_bf16x3_matches_fp32(ops, dev, models, n_rays, P):
+    """Split-bf16 (3x3, 6 MFMA) forward: same tolerances as the exact-fp32 MFMA path against the oracle, and
+    fp32-level agreement with the fp32 path itself."""
+    params, ms = models
+    rays = synth.blender_rays(n_rays, 3)
+    z = np.sort(synth.hash_uniform((n_rays, P), 9) * 4 + 2, -1).astype(np.float32)
+    m = ms[1]
+    out = N(ops.nerf_forward_rays_fast(m.packed(), m.packed_fast(), T(rays, dev), T(z, dev)))
+    sig = N(ops.nerf_forward_rays_fast(m.packed(), m.packed_fast(), T(rays, dev), T(z, dev), sigma_only=True))
+    ref = N(ops.nerf_forward_rays(m.packed(), T(rays, dev), T(z, dev)))
+    s_ref, rgb_ref, _ = O._field(params[1], rays, z, False, False)
+    np.testing.assert_allclose(out[:, 3].reshape(n_rays, P), s_ref, rtol=3e-5, atol=3e-5)
+    assert np.abs(out[:, :3].reshape(n_rays, P, 3) - rgb_ref).max() < 5e-6
+    np.testing.assert_allclose(sig[:, 0], out[:, 3], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-5)
+
+
+def test_render_rays_bf16x3(golden, dev, models):
+    import nerf_siren_amd
+    g = golden("g7_blender_test_time")
+    params, ms = models
+    nerf_siren_amd.set_math("bf16x3")
+    try:
+        res = _run_hip(g, dev, ms)
+    finally:
+        nerf_siren_amd.set_math("fp32")
+    for k in res:
+        err = np.abs(N(res[k]) - g["out_" + k]).reshape(g["rays"].shape[0], -1).max(-1)
+        tol = 1e-4 * (4.0 if "depth" in k else 1.0)
+        assert (err <= tol).mean() >= 0.65 and err.max() <= 100 * tol, (k, err.max())
+        if "coarse" in k:
+            assert err.max() <= tol
