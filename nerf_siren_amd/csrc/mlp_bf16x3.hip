@@ -38,34 +38,54 @@ __device__ __forceinline__ void split_block(const f32x16 &v, bf16x8 (&out)[2][3]
     }
 }
 
-// fast image: unit U = ((jb*KB + kb)*2 + s) -> 3 x 1 KiB: split i at bytes U*3072 + i*1024 + lane*16 (8 bf16)
-// built from the fp32 fragment image: the lane's floats of groups 2s and 2s+1 of (jb,kb) ARE its 8 k-slots.
+// fast image: per layer, unit U = (kb*2 + s)*JB + jb (input-block-major: a layer walks its INPUT blocks in the
+// outer loop, so each input block is split just before use and all JB accumulators advance together);
+// unit -> 3 x 1 KiB: split i at bytes (unit_base + U)*3072 + i*1024 + lane*16 (8 bf16).  Built from the fp32
+// fragment image: the lane's floats of groups 2s and 2s+1 of (jb,kb) ARE its 8 k-slots of k-step s.
+struct FastLayer { int off, JB, KB; };
+__constant__ FastLayer d_fast_layers[NL_FWD] = {
+    {OFF_L1, 8, 2}, {OFF_L2, 8, 8}, {OFF_L3, 8, 8}, {OFF_L4, 8, 8}, {OFF_L5, 8, 10},
+    {OFF_L6, 8, 8}, {OFF_L7, 8, 8}, {OFF_L8, 8, 8}, {OFF_FINAL, 8, 8}, {OFF_DIR, 4, 9}};
+
 __global__ void pack_bf16x3_kernel(const float *__restrict__ packed, __bf16 *__restrict__ fast) {
     const int n_units = OFF_SMALL / 512;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_units * 64; idx += gridDim.x * blockDim.x) {
-        const int U = idx >> 6, lane = idx & 63;
-        const f32x4 v0 = ldg4(packed + (int64_t)U * 512 + lane * 4), v1 = ldg4(packed + (int64_t)U * 512 + 256 + lane * 4);
+        const int Usrc = idx >> 6, lane = idx & 63;          // source unit in (jb,kb,s) order
+        int li = 0;
+#pragma unroll
+        for (int l = 1; l < NL_FWD; ++l)
+            if (Usrc * 512 >= d_fast_layers[l].off) li = l;
+        const FastLayer L = d_fast_layers[li];
+        const int rel = Usrc - L.off / 512;
+        const int s = rel & 1, kb = (rel >> 1) % L.KB, jb = (rel >> 1) / L.KB;
+        const int Udst = L.off / 512 + (kb * 2 + s) * L.JB + jb;
+        const f32x4 v0 = ldg4(packed + (int64_t)Usrc * 512 + lane * 4), v1 = ldg4(packed + (int64_t)Usrc * 512 + 256 + lane * 4);
         const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         bf16x8 sp[3];
         split8(x, sp);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            *reinterpret_cast<bf16x8 *>(fast + ((int64_t)U * 3 + i) * 512 + lane * 8) = sp[i];
+            *reinterpret_cast<bf16x8 *>(fast + ((int64_t)Udst * 3 + i) * 512 + lane * 8) = sp[i];
     }
 }
 
 // LDS ring of stages of US units (3 KiB each)
-constexpr int US = 8;                                  // units per stage -> 24 KiB
+#ifndef NERFMI_US
+#define NERFMI_US 8
+#endif
+constexpr int US = NERFMI_US;                          // units per stage
 constexpr int FSLOT = 3;
-constexpr int FLDS_BYTES = FSLOT * US * 3072;          // 72 KiB
+constexpr int FLDS_BYTES = FSLOT * US * 3072;
 constexpr int PIECES = US * 3;                         // 1 KiB pieces per stage
-constexpr int QP = PIECES / 4;                         // pieces per wave per stage (6)
+constexpr int QP = PIECES / 4;                         // pieces per wave per stage
 
-// acc[jb] = bias + W . [in0 ; in1] with six bf16 MFMAs per (block, k-step)
-template <int KB0, int KB1, int JB>
+// acc[jb] = bias + W . [in0 ; act(in1)] with six bf16 MFMAs per (output block, k-step).
+// in0 / in1 are fp32 blocks in accumulator layout; in1 is passed through ReLU when RELU1 (the previous layer's raw
+// outputs).  use(kb, v) is called with each in1 block as it is consumed (training: store + sign mask).
+template <int KB0, int KB1, int JB, bool RELU1, class Use>
 __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, const float *__restrict__ bias,
-                                             const bf16x8 (*in0)[2][3], const bf16x8 (*in1)[2][3], f32x16 *acc, char *wlds,
-                                             int wid, int lane) {
+                                             const f32x16 *in0, const f32x16 *in1, f32x16 *acc, char *wlds, int wid,
+                                             int lane, Use use) {
     constexpr int KBT = KB0 + KB1;
     constexpr int NU = JB * KBT * 2;                    // units in this layer
     constexpr int NP = NU * 3;                          // 1 KiB pieces
@@ -90,18 +110,30 @@ __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, c
     lwrite(0);
     if (NST > 1) gload(1);
 #pragma unroll
-    for (int jb = 0; jb < JB; ++jb) {
-        f32x16 c;
+    for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 b = ldg4(bias + 32 * jb + 8 * q);
-            c[4 * q + 0] = b[0]; c[4 * q + 1] = b[1]; c[4 * q + 2] = b[2]; c[4 * q + 3] = b[3];
+            acc[jb][4 * q + 0] = b[0]; acc[jb][4 * q + 1] = b[1]; acc[jb][4 * q + 2] = b[2]; acc[jb][4 * q + 3] = b[3];
         }
 #pragma unroll
-        for (int kb = 0; kb < KBT; ++kb) {
+    for (int kb = 0; kb < KBT; ++kb) {
+        // split this input block just before use: its VALU work issues in the shadow of the previous block's MFMAs
+        f32x16 v = (kb < KB0) ? in0[kb] : in1[kb - KB0];
+        if (kb >= KB0) {
+            if (RELU1) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int U = (jb * KBT + kb) * 2 + s;
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            use(kb - KB0, v);
+        }
+        bf16x8 bs[2][3];
+        split_block(v, bs);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb) {
+                const int U = (kb * 2 + s) * JB + jb;
                 const int stage = U / US, ul = U % US;
                 if (ul == 0) {
                     if (stage + 1 < NST) lwrite(stage + 1);
@@ -112,19 +144,15 @@ __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, c
                 const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(ap);
                 const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(ap + 1024);
                 const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(ap + 2048);
-                const bf16x8 b1 = (kb < KB0) ? in0[kb][s][0] : in1[kb - KB0][s][0];
-                const bf16x8 b2 = (kb < KB0) ? in0[kb][s][1] : in1[kb - KB0][s][1];
-                const bf16x8 b3 = (kb < KB0) ? in0[kb][s][2] : in1[kb - KB0][s][2];
-                // small terms first
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+                f32x16 c = acc[jb];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bs[s][0], c, 0, 0, 0);      // small terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[s][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bs[s][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bs[s][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[s][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[s][0], c, 0, 0, 0);
+                acc[jb] = c;
             }
-        }
-        acc[jb] = c;
     }
 }
 
@@ -171,16 +199,6 @@ __device__ __forceinline__ void embed_dir_block_f(float x, float y, float z, int
     }
 }
 
-__device__ __forceinline__ void relu_split8(const f32x16 (&acc)[8], bf16x8 (&hs)[8][2][3]) {
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        f32x16 v = acc[b];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-        split_block(v, hs[b]);
-    }
-}
-
 template <bool SIGMA_ONLY>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__restrict__ fast,
@@ -197,50 +215,48 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
     const float x = __fadd_rn(rr[0], __fmul_rn(rr[3], zz));
     const float y = __fadd_rn(rr[1], __fmul_rn(rr[4], zz));
     const float w = __fadd_rn(rr[2], __fmul_rn(rr[5], zz));
-    bf16x8 es[2][2][3], ds[1][2][3], hs[8][2][3];
-    {
-        f32x16 e[2];
-        embed_xyz_blocks_f(x, y, w, half, e);
-        split_block(e[0], es[0]);
-        split_block(e[1], es[1]);
-        if (!SIGMA_ONLY) {
-            f32x16 de;
-            embed_dir_block_f(rr[3], rr[4], rr[5], half, de);
-            split_block(de, ds[0]);
-        }
-    }
+    f32x16 e[2];
+    embed_xyz_blocks_f(x, y, w, half, e);
     const float *bias = packed + OFF_BIAS + 4 * half;
     auto img = [&](int off) { return fast + (int64_t)(off / 512) * 1536; };      // unit * 3 pieces * 512 bf16
-    f32x16 acc[8];
-    layer_bf16x3<2, 0, 8>(img(OFF_L1), bias, es, nullptr, acc, wlds, wid, lane);
-    relu_split8(acc, hs);
+    auto nouse = [](int, const f32x16 &) {};
+    f32x16 h[8], acc[8];
+    auto copy8 = [&]() {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) h[b] = acc[b];
+    };
+    layer_bf16x3<2, 0, 8, false>(img(OFF_L1), bias, e, nullptr, acc, wlds, wid, lane, nouse);
+    copy8();
     for (int l = 1; l <= 3; ++l) {
-        layer_bf16x3<8, 0, 8>(img(OFF_L2 + (l - 1) * SZ_HID), bias + 256 * l, hs, nullptr, acc, wlds, wid, lane);
-        relu_split8(acc, hs);
+        layer_bf16x3<0, 8, 8, true>(img(OFF_L2 + (l - 1) * SZ_HID), bias + 256 * l, nullptr, h, acc, wlds, wid, lane, nouse);
+        copy8();
     }
-    layer_bf16x3<2, 8, 8>(img(OFF_L5), bias + 256 * 4, es, hs, acc, wlds, wid, lane);
-    relu_split8(acc, hs);
+    layer_bf16x3<2, 8, 8, true>(img(OFF_L5), bias + 256 * 4, e, h, acc, wlds, wid, lane, nouse);
+    copy8();
     for (int l = 5; l <= 7; ++l) {                       // xyz_encoding_6..8
-        layer_bf16x3<8, 0, 8>(img(OFF_L6 + (l - 5) * SZ_HID), bias + 256 * l, hs, nullptr, acc, wlds, wid, lane);
-        relu_split8(acc, hs);
+        layer_bf16x3<0, 8, 8, true>(img(OFF_L6 + (l - 5) * SZ_HID), bias + 256 * l, nullptr, h, acc, wlds, wid, lane, nouse);
+        copy8();
     }
-    // sigma = w_sigma . relu(h8) + b from the fp32 accumulators of xyz_encoding_8 (nerf.py:112)
+    // h = raw outputs of xyz_encoding_8; sigma = w_sigma . relu(h) + b (nerf.py:112)
+    float sigma;
+    {
+        f32x16 h8[8];
 #pragma unroll
-    for (int b = 0; b < 8; ++b)
+        for (int b = 0; b < 8; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[b][r] = fmaxf(acc[b][r], 0.f);
-    const float sigma = dot_blocks<8>(acc, packed + OFF_W_SIGMA + 4 * half) + packed[OFF_B_SIGMA];
-    if (!SIGMA_ONLY) {
-        layer_bf16x3<8, 0, 8>(img(OFF_FINAL), bias + 256 * 8, hs, nullptr, acc, wlds, wid, lane);   // no activation
-#pragma unroll
-        for (int b = 0; b < 8; ++b) split_block(acc[b], hs[b]);
+            for (int r = 0; r < 16; ++r) h8[b][r] = fmaxf(h[b][r], 0.f);
+        sigma = dot_blocks<8>(h8, packed + OFF_W_SIGMA + 4 * half) + packed[OFF_B_SIGMA];
     }
     if (SIGMA_ONLY) {
         if (ok && half == 0) out[p] = sigma;
         return;
     }
-    f32x16 dh[4];
-    layer_bf16x3<8, 1, 4>(img(OFF_DIR), packed + OFF_BIAS_DIR + 4 * half, hs, ds, dh, wlds, wid, lane);
+    layer_bf16x3<0, 8, 8, true>(img(OFF_FINAL), bias + 256 * 8, nullptr, h, acc, wlds, wid, lane, nouse);
+    copy8();                                             // xyz_encoding_final: no activation on its output
+    f32x16 de[1], dh[4];
+    embed_dir_block_f(rr[3], rr[4], rr[5], half, de[0]);
+    // dir_encoding input = [final (no ReLU) | dir embedding]: the packed order is final first (mlp_layout.h)
+    layer_bf16x3<8, 1, 4, false>(img(OFF_DIR), packed + OFF_BIAS_DIR + 4 * half, h, de, dh, wlds, wid, lane, nouse);
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll

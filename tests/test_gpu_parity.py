@@ -679,3 +679,46 @@ def test_render_rays_bf16x3(golden, dev, models):
         assert (err <= tol).mean() >= 0.65 and err.max() <= 100 * tol, (k, err.max())
         if "coarse" in k:
             assert err.max() <= tol
+
+
+# --------------------------------------------------------------------------- harness (callers of the path)
+def test_system_harness_and_checkpoint(tmp_path, dev, models):
+    """NeRFSystem-shaped loop (system.py:172-306) on the HIP path + Lightning-style checkpoint key prefixes."""
+    from types import SimpleNamespace
+    from nerf_siren_amd.system import NeRFSystem, batched_inference, load_ckpt
+    params, ms = models
+    hp = SimpleNamespace(loss_type='mse', N_samples=64, N_importance=64, use_disp=False, perturb=1.0, noise_std=0.0,
+                         chunk=128, optimizer='adam', lr=5e-4, momentum=0.9, weight_decay=0, lr_scheduler='steplr',
+                         decay_step=[2, 4, 8], decay_gamma=0.5, num_epochs=16, pretrained=None)
+    # a Lightning checkpoint as the reference writes it: keys 'nerf_coarse.xyz_encoding_1.0.weight', ...
+    sd = {f"nerf_coarse.{k}": torch.from_numpy(v) for k, v in params[0].items()}
+    sd.update({f"nerf_fine.{k}": torch.from_numpy(v) for k, v in params[1].items()})
+    ck = tmp_path / "epoch=0.ckpt"
+    torch.save({"state_dict": sd, "epoch": 0}, ck)
+    hp.pretrained = str(ck)
+    system = NeRFSystem(hp, white_back=True).to(dev)
+    assert torch.equal(system.nerf_fine.sigma.weight.cpu(), torch.from_numpy(params[1]["sigma.weight"]))
+    (opt,), (sched,) = system.configure_optimizers()
+    rays = T(synth.blender_rays(300, 41), dev)
+    rgbs = T(synth.hash_uniform((300, 3), 42), dev)
+    losses = []
+    for it in range(3):
+        out = system.training_step({"rays": rays, "rgbs": rgbs}, it)          # 300 rays in chunks of 128
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+        losses.append(float(out["loss"].detach()))
+    assert losses[-1] < losses[0] and torch.isfinite(out["log"]["train/psnr"])
+    val = system.validation_step({"rays": rays[None], "rgbs": rgbs[None]}, 0)
+    ep = system.validation_epoch_end([val, val])
+    assert torch.isfinite(ep["log"]["val/psnr"])
+    # eval.py:70-103 -- whole "image" in chunks == one call
+    r1 = batched_inference(system.models, system.embeddings, rays, 64, 64, False, 128, True)
+    from nerf_siren_amd import render_rays
+    with torch.no_grad():
+        r2 = render_rays(system.models, system.embeddings, rays, 64, False, 0, 0, 64, 1 << 15, True, test_time=True)
+    for k in r2:
+        assert torch.equal(r1[k], r2[k])
+    other = NeRFSystem(SimpleNamespace(**{**vars(hp), "pretrained": None}), white_back=True)
+    load_ckpt(other.nerf_coarse, str(ck), model_name='nerf_coarse')
+    assert torch.equal(other.nerf_coarse.rgb[0].bias, torch.from_numpy(params[0]["rgb.0.bias"]))
