@@ -54,11 +54,11 @@ __global__ void pack_kernel(ParamPtrs P, float *__restrict__ packed) {
             else if (idx < OFF_W_RGB) v = (idx == OFF_B_SIGMA) ? P.p[PARAM_SIGMA_B][0] : 0.f;
             else if (idx < OFF_B_RGB) v = P.p[PARAM_RGB_W][idx - OFF_W_RGB];
             else v = (idx - OFF_B_RGB < 3) ? P.p[PARAM_RGB_B][idx - OFF_B_RGB] : 0.f;
-        } else {
-            int li = 1;
+        } else if (idx < PACKED_FLOATS - STREAM_TAIL) {
+            int li = 1;                                 // the transposed images are stored in backward order
 #pragma unroll
             for (int l = 2; l < NL_FWD; ++l)
-                if (idx >= d_layers[l].t_off) li = l;
+                if (idx >= d_layers[l].t_off && idx < d_layers[l].t_off + d_layers[l].t_KBO * d_layers[l].JB * 1024) li = l;
             const LayerDesc L = d_layers[li];
             const int JBc = L.JB;                       // contraction blocks = output blocks of W
             const int rel = idx - L.t_off;
@@ -118,6 +118,21 @@ __device__ __forceinline__ void embed_dir_block(float x, float y, float z, int h
     }
 }
 
+// Experiment builds (-DNERFMI_TIMING) stamp the shader clock at layer boundaries for a few workgroups.
+#ifdef NERFMI_TIMING
+__device__ unsigned long long nerfmi_dbg_ts[64 * 16];
+#define NERFMI_TS(i)                                                                                        \
+    do {                                                                                                    \
+        if ((threadIdx.x == 0) && (blockIdx.x % 48 == 0) && (blockIdx.x / 48 < 32)) {                       \
+            nerfmi_dbg_ts[(blockIdx.x / 48) * 16 + (i)] = __builtin_readcyclecounter();                     \
+            if ((i) == 1) nerfmi_dbg_ts[(blockIdx.x / 48) * 16 + 13] = wall_clock64();                      \
+            if ((i) == 12) nerfmi_dbg_ts[(blockIdx.x / 48) * 16 + 14] = wall_clock64();                     \
+        }                                                                                                   \
+    } while (0)
+#else
+#define NERFMI_TS(i) do { } while (0)
+#endif
+
 template <bool EMBEDDED, bool SIGMA_ONLY, bool SAVE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ rays, const float *__restrict__ z,
@@ -125,6 +140,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
                     float *__restrict__ saved, int64_t ld) {
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
+    NERFMI_TS(0);
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t p0 = wave * 32;
     // no early exit: the four waves of a workgroup share the weight stream through LDS (barriers); a wave
@@ -133,7 +149,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
     const bool ok = praw < n_points;
     const int64_t p = ok ? praw : n_points - 1;
     RowImage S;
-    S.init(saved, wave, SAVED_ROWS, lane, ok, p0 < n_points);
+    S.init(saved, wave, ld / 32, SAVED_ROWS, lane, ok, p0 < n_points);
 
     f32x16 e[2], de[1];
     if (EMBEDDED) {
@@ -174,6 +190,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
     const int wid = threadIdx.x >> 6;
     const float *bias = packed + OFF_BIAS + 4 * half;
     f32x16 h[8], acc[8];
+    NERFMI_TS(1);
 
     // Stores share the in-order vmcnt queue with the weight loads: a wait for a weight fragment issued
     // after a store also waits for that store's acknowledgement, so the training variant keeps more
@@ -196,45 +213,49 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         for (int b = 0; b < 8; ++b) h[b] = acc[b];
     };
 
-    layer_mfma_lds<2, 0, 8>(packed + OFF_L1, bias, e, nullptr, acc, no_pre, relu_epi(S_H), wlds, wid, lane);
+    WeightStage ws;
+    layer_mfma_lds<2, 0, 8, 0, true>(packed + OFF_L1, bias, e, nullptr, acc, no_pre, relu_epi(S_H), wlds, ws, wid, lane);
     if (SAVE) store_mask(S, 0, mk);
     copy8();
+    NERFMI_TS(2);
     for (int l = 1; l <= 3; ++l) {
-        layer_mfma_lds<8, 0, 8>(packed + OFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, relu_epi(S_H + 256 * l), wlds, wid, lane);
+        layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, relu_epi(S_H + 256 * l), wlds, ws, wid, lane);
         if (SAVE) store_mask(S, l, mk);
         copy8();
+        NERFMI_TS(2 + l);
     }
-    layer_mfma_lds<2, 8, 8>(packed + OFF_L5, bias + 256 * 4, e, h, acc, no_pre, relu_epi(S_H + 256 * 4), wlds, wid, lane);
+    layer_mfma_lds<2, 8, 8, 0, false>(packed + OFF_L5, bias + 256 * 4, e, h, acc, no_pre, relu_epi(S_H + 256 * 4), wlds, ws, wid, lane);
     if (SAVE) store_mask(S, 4, mk);
     copy8();
+    NERFMI_TS(6);
 
-    float sigma = 0.f;
-    for (int l = 5; l <= 8; ++l) {   // xyz_encoding_6..8, then xyz_encoding_final (no ReLU)
-        if (l == 8) {
-            sigma = dot_blocks<8>(h, packed + OFF_W_SIGMA + 4 * half) + packed[OFF_B_SIGMA];
-            if (SIGMA_ONLY) break;
-        }
-        const bool last = (l == 8);
-        const int row0 = last ? S_FINAL : S_H + 256 * l;
-        layer_mfma_lds<8, 0, 8>(packed + OFF_L6 + (l - 5) * SZ_HID, bias + 256 * l, h, nullptr, acc,
-                            no_pre, [&S, &mk, row0, last](int jb, int q, f32x4 c, int) {
-                                if (!last) c = relu4(c);
-                                if (SAVE) {
-                                    if (!last) mask_or(mk, jb, q, c);
-                                    store_slice(S, row0 + 32 * jb, q, c);
-                                }
-                                return c;
-                            }, wlds, wid, lane);
-        if (SAVE && !last) store_mask(S, l, mk);
+    for (int l = 5; l <= 7; ++l) {   // xyz_encoding_6..8
+        layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_L6 + (l - 5) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre,
+                                          relu_epi(S_H + 256 * l), wlds, ws, wid, lane);
+        if (SAVE) store_mask(S, l, mk);
         copy8();
+        NERFMI_TS(2 + l);
+    }
+    const float sigma = dot_blocks<8>(h, packed + OFF_W_SIGMA + 4 * half) + packed[OFF_B_SIGMA];   // nerf.py:112
+    if (!SIGMA_ONLY) {
+        // xyz_encoding_final: no activation (nerf.py:116).  A call of its own rather than a fourth trip of the
+        // loop above: a run-time "last layer" flag inside the epilogue would put a branch around every slice
+        layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_FINAL, bias + 256 * 8, h, nullptr, acc, no_pre,
+                                          [&S](int jb, int q, f32x4 c, int) {
+                                              if (SAVE) store_slice(S, S_FINAL + 32 * jb, q, c);
+                                              return c;
+                                          }, wlds, ws, wid, lane);
+        copy8();
+        NERFMI_TS(10);
     }
     if (SIGMA_ONLY) {
         if (ok && half == 0) out[p] = sigma;
         return;
     }
     f32x16 dh[4];
-    layer_mfma_lds<8, 1, 4>(packed + OFF_DIR, packed + OFF_BIAS_DIR + 4 * half, h, de, dh, no_pre, relu_epi(S_DIRH), wlds, wid, lane);
+    layer_mfma_lds<8, 1, 4, 0, false>(packed + OFF_DIR, packed + OFF_BIAS_DIR + 4 * half, h, de, dh, no_pre, relu_epi(S_DIRH), wlds, ws, wid, lane);
     if (SAVE) store_mask(S, 8, mk);
+    NERFMI_TS(11);
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -251,6 +272,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         *S.at(S_RGB + 1) = ok ? rgb[1] : 0.f;
         *S.at(S_RGB + 2) = ok ? rgb[2] : 0.f;
     }
+    NERFMI_TS(12);
 }
 
 static inline int64_t pad_points(int64_t n) { return (n + 31) / 32 * 32; }
@@ -260,6 +282,12 @@ static inline int64_t pad_points(int64_t n) { return (n + 31) / 32 * 32; }
 using namespace nerfmi;
 
 extern "C" {
+
+#ifdef NERFMI_TIMING
+int nerfmi_debug_timing(unsigned long long *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(nerfmi_dbg_ts), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 size_t nerfmi_nerf_packed_floats(void) { return (size_t)PACKED_FLOATS; }
 
@@ -274,7 +302,8 @@ int nerfmi_nerf_pack(const float *const *params, float *packed, nerfmi_stream_t 
     return check_launch("nerf_pack");
 }
 
-size_t nerfmi_nerf_saved_floats(int64_t n_points) { return (size_t)SAVED_ROWS * (size_t)pad_points(n_points); }
+// + one dump tile for waves past the end (mlp_core.h RowImage)
+size_t nerfmi_nerf_saved_floats(int64_t n_points) { return (size_t)SAVED_ROWS * (size_t)(pad_points(n_points) + 32); }
 
 int nerfmi_nerf_forward_rays(const float *packed, const float *rays, const float *z, int n_rays, int n_per_ray,
                              int sigma_only, float *out, float *saved, nerfmi_stream_t stream) {

@@ -109,6 +109,8 @@ __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, c
     gload(0);
     lwrite(0);
     if (NST > 1) gload(1);
+    bf16x8 an[3];
+    bf16x8 bs[2][3];
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
@@ -127,23 +129,43 @@ __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, c
             }
             use(kb - KB0, v);
         }
-        bf16x8 bs[2][3];
+#ifdef FX_NOSPLIT
+        if (kb == 0) split_block(v, bs);
+#else
         split_block(v, bs);
+#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int jb = 0; jb < JB; ++jb) {
                 const int U = (kb * 2 + s) * JB + jb;
                 const int stage = U / US, ul = U % US;
+                // Stage boundary: stage+1 goes to LDS, stage+2's loads are issued -- and NO barrier here.  The one
+                // barrier per stage sits in the MIDDLE of the stage: it publishes the slot written at this
+                // boundary (needed only at the next boundary) and protects the slot the next boundary will
+                // overwrite (last read in stage-1, which every wave has left by then).  Crossing a boundary
+                // therefore never drains the matrix pipe: the next stage's fragments are already visible and
+                // can be read ahead.
                 if (ul == 0) {
+#ifndef FX_NOSTREAM
                     if (stage + 1 < NST) lwrite(stage + 1);
                     if (stage + 2 < NST) gload(stage + 2);
-                    __syncthreads();
+#endif
+                    if (stage == 0) __syncthreads();            // first stage of the layer: written just above
                 }
-                const char *ap = lsrc + ((stage % FSLOT) * PIECES + ul * 3) * 1024;
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(ap);
-                const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(ap + 1024);
-                const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(ap + 2048);
+#ifndef FX_NOBAR
+                if (ul == US / 2 && NST > 1) __syncthreads();
+#endif
+                // weight fragments are read one unit ahead (two register sets), so a unit's LDS latency hides
+                // behind the previous unit's six MFMAs
+                auto lread = [&](int uu, int t) {
+                    return *reinterpret_cast<const bf16x8 *>(lsrc + (((uu / US) % FSLOT) * PIECES + (uu % US) * 3 + t) * 1024);
+                };
+                if (U == 0) { an[0] = lread(0, 0); an[1] = lread(0, 1); an[2] = lread(0, 2); }
+                const bf16x8 a1 = an[0], a2 = an[1], a3 = an[2];
+#ifndef FX_NOLDSR
+                if (U + 1 < NU) { an[0] = lread(U + 1, 0); an[1] = lread(U + 1, 1); an[2] = lread(U + 1, 2); }
+#endif
                 f32x16 c = acc[jb];
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bs[s][0], c, 0, 0, 0);      // small terms first
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[s][2], c, 0, 0, 0);
@@ -199,6 +221,18 @@ __device__ __forceinline__ void embed_dir_block_f(float x, float y, float z, int
     }
 }
 
+// Experiment builds (-DNERFMI_TIMING) stamp the shader clock at layer boundaries for a few workgroups.
+#ifdef NERFMI_TIMING
+__device__ unsigned long long nerfmi_dbg_ts_fast[64 * 16];
+#define NERFMI_TSF(i)                                                                                       \
+    do {                                                                                                    \
+        if ((threadIdx.x == 0) && (blockIdx.x % 32 == 0) && (blockIdx.x / 32 < 32))                         \
+            nerfmi_dbg_ts_fast[(blockIdx.x / 32) * 16 + (i)] = __builtin_readcyclecounter();                \
+    } while (0)
+#else
+#define NERFMI_TSF(i) do { } while (0)
+#endif
+
 template <bool SIGMA_ONLY>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__restrict__ fast,
@@ -206,6 +240,7 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
                            int n_per_ray, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char wlds[];
     const int lane = threadIdx.x & 63, half = lane >> 5, wid = threadIdx.x >> 6;
+    NERFMI_TSF(0);
     const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
     const int64_t praw = wave * 32 + (lane & 31);
     const bool ok = praw < n_points;
@@ -225,17 +260,22 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
 #pragma unroll
         for (int b = 0; b < 8; ++b) h[b] = acc[b];
     };
+    NERFMI_TSF(1);
     layer_bf16x3<2, 0, 8, false>(img(OFF_L1), bias, e, nullptr, acc, wlds, wid, lane, nouse);
     copy8();
+    NERFMI_TSF(2);
     for (int l = 1; l <= 3; ++l) {
         layer_bf16x3<0, 8, 8, true>(img(OFF_L2 + (l - 1) * SZ_HID), bias + 256 * l, nullptr, h, acc, wlds, wid, lane, nouse);
         copy8();
+        NERFMI_TSF(2 + l);
     }
     layer_bf16x3<2, 8, 8, true>(img(OFF_L5), bias + 256 * 4, e, h, acc, wlds, wid, lane, nouse);
     copy8();
+    NERFMI_TSF(6);
     for (int l = 5; l <= 7; ++l) {                       // xyz_encoding_6..8
         layer_bf16x3<0, 8, 8, true>(img(OFF_L6 + (l - 5) * SZ_HID), bias + 256 * l, nullptr, h, acc, wlds, wid, lane, nouse);
         copy8();
+        NERFMI_TSF(2 + l);
     }
     // h = raw outputs of xyz_encoding_8; sigma = w_sigma . relu(h) + b (nerf.py:112)
     float sigma;
@@ -253,10 +293,12 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
     }
     layer_bf16x3<0, 8, 8, true>(img(OFF_FINAL), bias + 256 * 8, nullptr, h, acc, wlds, wid, lane, nouse);
     copy8();                                             // xyz_encoding_final: no activation on its output
+    NERFMI_TSF(10);
     f32x16 de[1], dh[4];
     embed_dir_block_f(rr[3], rr[4], rr[5], half, de[0]);
     // dir_encoding input = [final (no ReLU) | dir embedding]: the packed order is final first (mlp_layout.h)
     layer_bf16x3<8, 1, 4, false>(img(OFF_DIR), packed + OFF_BIAS_DIR + 4 * half, h, de, dh, wlds, wid, lane, nouse);
+    NERFMI_TSF(11);
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -272,6 +314,7 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
         o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2]; o.w = sigma;
         reinterpret_cast<float4 *>(out)[p] = o;
     }
+    NERFMI_TSF(12);
 }
 
 }  // namespace nerfmi
@@ -279,6 +322,12 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
 using namespace nerfmi;
 
 extern "C" {
+
+#ifdef NERFMI_TIMING
+int nerfmi_debug_timing_fast(unsigned long long *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(nerfmi_dbg_ts_fast), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 size_t nerfmi_nerf_fast_bytes(void) { return (size_t)(OFF_SMALL / 512) * 3072; }
 

@@ -41,8 +41,8 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
     const int64_t praw = p0 + (lane & 31);
     const bool ok = praw < n_points;
     RowImage S, Wk;
-    S.init(const_cast<float *>(saved), wave, SAVED_ROWS, lane, ok, live);
-    Wk.init(work, wave, W_ROWS, lane, ok, live);
+    S.init(const_cast<float *>(saved), wave, ld / 32, SAVED_ROWS, lane, ok, live);
+    Wk.init(work, wave, ld / 32, W_ROWS, lane, ok, live);
 
     float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) go = reinterpret_cast<const float4 *>(grad_out)[praw];
@@ -54,9 +54,9 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
         for (int c = 0; c < 3; ++c) {
             const float rgb = *S.at(S_RGB + c);
             dpre[c] = g3[c] * rgb * (1.0f - rgb);
-                if (half == 0 && live) *Wk.at(W_DRGB + c) = dpre[c];
+            if (half == 0) *Wk.at(W_DRGB + c) = dpre[c];
         }
-        if (half == 0 && live) *Wk.at(W_DSIG) = go.w;
+        if (half == 0) *Wk.at(W_DSIG) = go.w;
     }
     const float dsig = go.w;
 
@@ -84,16 +84,17 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
     __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
     const int wid = threadIdx.x >> 6;
     // d final = W_dir[:, :256]^T dZ_dir                          (nerf.py:116-118; no activation on final)
-    layer_mfma_lds<4, 0, 8>(packed + OFF_TDIR, nullptr, dz, nullptr, acc, [](int) { return 0; },
+    WeightStage ws;
+    layer_mfma_lds<4, 0, 8, 0, true>(packed + OFF_TDIR, nullptr, dz, nullptr, acc, [](int) { return 0; },
                             [&Wk](int jb, int q, f32x4 c, int) {
                                 store_slice(Wk, W_DFINAL + 32 * jb, q, c);
                                 return c;
-                            }, wlds, wid, lane);
+                            }, wlds, ws, wid, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) dz[b] = acc[b];
     // d h8 = W_final^T d final + w_sigma d sigma, masked by h8 > 0 (nerf.py:112-116)
     load_mask(S, 7, mk);
-    layer_mfma_lds<8, 0, 8>(packed + OFF_TFINAL, nullptr, dz, nullptr, acc, [](int) { return 0; },
+    layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_TFINAL, nullptr, dz, nullptr, acc, [](int) { return 0; },
                              [&](int jb, int q, f32x4 c, int) {
                                  const f32x4 w = ldg4(packed + OFF_W_SIGMA + 32 * jb + 8 * q + 4 * half);
 #pragma unroll
@@ -103,20 +104,20 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
                                  }
                                  store_slice(Wk, W_DZ + 7 * 256 + 32 * jb, q, c);
                                  return c;
-                             }, wlds, wid, lane);
+                             }, wlds, ws, wid, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) dz[b] = acc[b];
     // xyz_encoding_8 .. xyz_encoding_2: d h_{l-1} = W_l[:, hidden]^T dZ_l, masked by h_{l-1} > 0
     for (int li = 7; li >= 1; --li) {
         const int wrow = W_DZ + (li - 1) * 256;
         load_mask(S, li - 1, mk);
-        layer_mfma_lds<8, 0, 8>(packed + OFF_T2 + (li - 1) * SZ_HID, nullptr, dz, nullptr, acc, [](int) { return 0; },
+        layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_T8 + (7 - li) * SZ_HID, nullptr, dz, nullptr, acc, [](int) { return 0; },
                                  [&](int jb, int q, f32x4 c, int) {
 #pragma unroll
                                      for (int t = 0; t < 4; ++t) c[t] = mask_bit(mk, jb, q, t) ? c[t] : 0.f;
                                      store_slice(Wk, wrow + 32 * jb, q, c);
                                      return c;
-                                 }, wlds, wid, lane);
+                                 }, wlds, ws, wid, lane);
 #pragma unroll
         for (int b = 0; b < 8; ++b) dz[b] = acc[b];
     }
@@ -354,7 +355,9 @@ static DwPlan make_plan(int64_t ld) {
     // chunks proportional to MFMA work so that every workgroup costs the same and the grid is <= 256 (one per CU)
     // cost per 32-point tile ~ MFMA cycles + ~1.5k cycles of staging/barriers (measured: the small tasks were
     // the critical path when sized by MFMA work alone)
-    static const int base[6] = {23, 8, 13, 4, 4, 5};
+    // 8 x 26 + 2 x 9 + 14 + 5 + 5 + 6 = 256 workgroups: every CU gets exactly one (the LDS tiles of a workgroup
+    // fill a CU), so the kernel takes one workgroup's time; leaving CUs without a chunk costs their share outright
+    static const int base[6] = {26, 9, 14, 5, 5, 6};
     const int64_t tiles = ld / 32;
     int wg = 0, off = 0;
     for (int i = 0; i < n; ++i) {
@@ -385,7 +388,7 @@ extern "C" {
 size_t nerfmi_nerf_backward_workspace_floats(int64_t n_points) {
     const int64_t ld = pad_points(n_points < 1 ? 1 : n_points);
     const DwPlan P = make_plan(ld);
-    return (size_t)W_ROWS * (size_t)ld + plan_partial_floats(P);
+    return (size_t)W_ROWS * (size_t)(ld + 32) + plan_partial_floats(P);   // + the dump tile (mlp_core.h RowImage)
 }
 
 int nerfmi_nerf_backward_rays(const float *packed, const float *rays, const float *z, int n_rays, int n_per_ray,
@@ -403,7 +406,7 @@ int nerfmi_nerf_backward_rays(const float *packed, const float *rays, const floa
     }
     hipStream_t st = (hipStream_t)stream;
     float *work = workspace;
-    float *partial = workspace + (size_t)W_ROWS * ld;
+    float *partial = workspace + (size_t)W_ROWS * (ld + 32);
     const int64_t waves = (n_points + 31) / 32;
     hipLaunchKernelGGL(nerf_backward_chain_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
                        grad_out, n_points, ld, work);

@@ -111,45 +111,66 @@ __device__ __forceinline__ void layer_mfma(const float *__restrict__ wp, const f
 // wave's vector-memory operations retire IN ORDER, anything slow in that queue (an activation store, an HBM
 // load) then stalls the next weight wait.  Here the four waves, which all walk the same packed image, fetch
 // a quarter each: the stream is cut into stages of GS fragments (16 KiB); at a stage boundary a wave
-// (1) writes the quarter it loaded ONE boundary ago into LDS slot (s+1)%3, (2) issues the global loads of
-// stage s+2 into 16 VGPRs, (3) passes one barrier, then runs stage s from LDS (ds_read_b128 per four
-// MFMAs).  A load is issued ~4k cycles before its data is touched and ~8k before it is consumed; three
-// slots make one barrier per stage sufficient (slot (s+1)%3 was last read in stage s-2, which every wave
-// finished before the previous barrier).
+// (1) writes the quarter it loaded ONE boundary ago into LDS slot (s+1)%4, (2) issues the global loads of
+// stage s+2 into 16 VGPRs, then runs stage s from LDS (ds_read_b128 per four MFMAs, read one group ahead);
+// the single barrier per stage sits in the MIDDLE of the stage: it publishes the slot written at this
+// stage's boundary (read from the next boundary on) and protects the slot the next boundary overwrites.
+//
+// The stream does not stop at a layer's end: the images of consecutive layers are contiguous in `packed` in
+// execution order (mlp_layout.h), so stages NST and NST+1 of a layer ARE stages 0 and 1 of the next one.  A
+// layer that is not the first of its kernel (FIRST = false) finds its stage 0 already published in LDS and
+// its stage 1 in the staging registers `st` -- no cold start (two serialized L2 round trips + a barrier)
+// per layer, and the loads keep flying during the epilogue between layers.  PH is the ring phase of the
+// layer's stage 0 (slot = (stage + PH) % 4); layers called from a runtime loop need NST % 4 == 0.  After
+// the last layer the two prefetched stages are simply never used (they read valid bytes of `packed`).
 // ---------------------------------------------------------------------------------------------------
 #ifndef NERFMI_GS
 #define NERFMI_GS 16
 #endif
 constexpr int GS = NERFMI_GS;              // fragments (1 KiB each) per stage
-constexpr int NSLOT = 3;
-constexpr int WLDS_FLOATS = NSLOT * GS * 256;   // 48 KiB
+constexpr int NSLOT = 4;
+constexpr int WLDS_FLOATS = NSLOT * GS * 256;   // 64 KiB
+constexpr int QS = GS / 4;                 // fragments per wave per stage
 
-template <int KB0, int KB1, int JB, class Pre, class Epi>
+struct WeightStage {
+    f32x4 st[QS];                          // this wave's quarter of the stage in flight
+};
+
+template <int KB0, int KB1, int JB>
+constexpr int layer_stages() { return JB * (KB0 + KB1) * 4 / GS; }
+
+template <int KB0, int KB1, int JB, int PH, bool FIRST, class Pre, class Epi>
 __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, const float *__restrict__ bias,
                                                const f32x16 *in0, const f32x16 *in1, f32x16 *out, Pre pre, Epi epi,
-                                               float *wlds, int wid, int lane) {
+                                               float *wlds, WeightStage &ws, int wid, int lane) {
     constexpr int KBT = KB0 + KB1;
     constexpr int G = JB * KBT * 4;
-    constexpr int NST = (G + GS - 1) / GS;                          // the last stage may be partial
-    constexpr int QS = GS / 4;                                      // fragments per wave per stage
+    static_assert(G % GS == 0, "a layer is a whole number of stages");
+    constexpr int NST = G / GS;
     const float *gsrc = wbase + (QS * wid) * 256 + lane * 4;        // this wave's quarter of every stage
     float *ldst = wlds + (QS * wid) * 256 + lane * 4;
     const float *lsrc = wlds + lane * 4;
-    f32x4 st[QS];
-    auto gload = [&](int stage) {
+    auto gload = [&](int stage) {                                   // stage >= NST: the next layer's image
 #pragma unroll
-        for (int i = 0; i < QS; ++i)
-            if ((stage + 1) * GS <= G || stage * GS + QS * wid + i < G) st[i] = ldg4(gsrc + (stage * GS + i) * 256);
+        for (int i = 0; i < QS; ++i) ws.st[i] = ldg4(gsrc + (stage * GS + i) * 256);
     };
     auto lwrite = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < QS; ++i) *reinterpret_cast<f32x4 *>(ldst + ((stage % NSLOT) * GS + i) * 256) = st[i];
+        for (int i = 0; i < QS; ++i)
+            *reinterpret_cast<f32x4 *>(ldst + (((stage + PH) % NSLOT) * GS + i) * 256) = ws.st[i];
     };
-    __syncthreads();                       // every wave is done reading the previous layer's slots
-    gload(0);
-    lwrite(0);
-    if (NST > 1) gload(1);
+    auto lread = [&](int g) {
+        return *reinterpret_cast<const f32x4 *>(lsrc + (((g / GS + PH) % NSLOT) * GS + g % GS) * 256);
+    };
+    if (FIRST) {
+        __syncthreads();
+        gload(0);
+        lwrite(0);
+        gload(1);
+        __syncthreads();
+    }
     f32x16 c_prev;
+    f32x4 a_next;
     decltype(pre(0)) pv_prev = pre(0);
     auto run_slice = [&](int jb, int q, const f32x16 &c, decltype(pre(0)) pv) {
         const f32x4 o = epi(jb, q, f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}, pv);
@@ -177,11 +198,14 @@ __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, 
                 const int g = (jb * KBT + kb) * 4 + q;
                 const int stage = g / GS, gl = g % GS;
                 if (gl == 0) {                                   // stage boundary (resolved at compile time)
-                    if (stage + 1 < NST) lwrite(stage + 1);
-                    if (stage + 2 < NST) gload(stage + 2);
-                    __syncthreads();
+                    lwrite(stage + 1);
+                    gload(stage + 2);
                 }
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(lsrc + ((stage % NSLOT) * GS + gl) * 256);
+                if (gl == GS / 2) __syncthreads();
+                // fragments are read ONE group ahead (two register sets): the LDS latency of group g+1 hides
+                // behind group g's four MFMAs instead of draining the pipe in front of every group
+                const f32x4 a = (g == 0) ? lread(0) : a_next;
+                if (g + 1 < G) a_next = lread(g + 1);
                 c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], B[4 * q + 0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], B[4 * q + 1], c, 0, 0, 0);
                 const int gq = kb * 4 + q;
@@ -230,9 +254,14 @@ struct RowImage {
     int lane;
     unsigned lane_off;   // (4*half + (lane&3))*32 + 4*((lane&31)>>2): unit 4*half+(lane&3), points 4m..4m+3
     bool ok;             // point < n_points (columns beyond n_points are written as 0)
-    bool live;           // the wave owns at least one real point (a wave past the end must not store at all)
-    __device__ __forceinline__ void init(float *base, int64_t tile_idx, int rows, int lane_, bool ok_, bool live_) {
-        tile = base + (live_ ? tile_idx : 0) * (int64_t)(rows * 32);
+    bool live;           // the wave owns at least one real point
+    // A wave past the end (it exists because the workgroup's waves share barriers) is pointed at the DUMP
+    // tile, one spare tile behind the image's n_tiles real ones, so that the stores in the layers' epilogues
+    // need no branch: a branch per store would cut the straight-line MFMA stream into basic blocks and pin the
+    // epilogue's vector work between them instead of letting it issue in the MFMAs' shadow.
+    __device__ __forceinline__ void init(float *base, int64_t tile_idx, int64_t n_tiles, int rows, int lane_, bool ok_,
+                                         bool live_) {
+        tile = base + (live_ ? tile_idx : n_tiles) * (int64_t)(rows * 32);
         lane = lane_;
         lane_off = (unsigned)((4 * (lane_ >> 5) + (lane_ & 3)) * 32 + 4 * ((lane_ & 31) >> 2));
         ok = ok_;
@@ -244,13 +273,15 @@ struct RowImage {
 
 // store registers 4q..4q+3 of a block (units row0 + 8q + 4*half + {0..3}, row0 = block's first row)
 __device__ __forceinline__ void store_slice(const RowImage &im, int row0, int q, f32x4 v) {
-    if (!im.live) return;
     float x[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) x[t] = im.ok ? v[t] : 0.f;
     quad_transpose(x, im.lane);
     // streamed once, read back by a later kernel: non-temporal so the 1.3 GB activation stream does not
     // displace the L2-resident weights
+#ifdef FX_NOSTORE
+    if (x[0] == 123.456f)
+#endif
     __builtin_nontemporal_store(f32x4{x[0], x[1], x[2], x[3]},
                                 reinterpret_cast<f32x4 *>(im.tile + (row0 + 8 * q) * 32 + im.lane_off));
 }
@@ -298,8 +329,7 @@ __device__ __forceinline__ bool mask_bit(const unsigned (&mk)[4], int jb, int q,
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_mask(const RowImage &im, int layer, unsigned (&mk)[4]) {
-    if (im.live)
-        *reinterpret_cast<u32x4 *>(im.tile + (S_MASK + 8 * layer) * 32 + 4 * im.lane) = u32x4{mk[0], mk[1], mk[2], mk[3]};
+    *reinterpret_cast<u32x4 *>(im.tile + (S_MASK + 8 * layer) * 32 + 4 * im.lane) = u32x4{mk[0], mk[1], mk[2], mk[3]};
     mk[0] = mk[1] = mk[2] = mk[3] = 0u;
 }
 __device__ __forceinline__ void load_mask(const RowImage &im, int layer, unsigned (&mk)[4]) {

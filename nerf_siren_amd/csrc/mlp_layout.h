@@ -69,18 +69,22 @@ constexpr int OFF_B_SIGMA = OFF_W_SIGMA + 256;             // 1 (+3 pad)
 constexpr int OFF_W_RGB = OFF_B_SIGMA + 4;                 // 3 x 128
 constexpr int OFF_B_RGB = OFF_W_RGB + 384;                 // 3 (+1 pad)
 constexpr int OFF_TRANS = OFF_B_RGB + 4;
-// transposed images (backward): layers 2..8 hidden part, final, dir(final part)
-constexpr int OFF_T2 = OFF_TRANS;
-constexpr int OFF_T3 = OFF_T2 + SZ_HID;
-constexpr int OFF_T4 = OFF_T3 + SZ_HID;
-constexpr int OFF_T5 = OFF_T4 + SZ_HID;
-constexpr int OFF_T6 = OFF_T5 + SZ_HID;
-constexpr int OFF_T7 = OFF_T6 + SZ_HID;
-constexpr int OFF_T8 = OFF_T7 + SZ_HID;
-constexpr int OFF_TFINAL = OFF_T8 + SZ_HID;
-constexpr int OFF_TDIR = OFF_TFINAL + SZ_HID;              // 8 kbo x 4 jb
+// transposed images (backward): dir(final part), final, layers 8..2 hidden part -- stored in the ORDER THE
+// BACKWARD CHAIN WALKS THEM, so that its weight stream runs across layer ends exactly like the forward one
+// (mlp_core.h layer_mfma_lds)
+constexpr int OFF_TDIR = OFF_TRANS;                        // 8 kbo x 4 jb
 constexpr int SZ_TDIR = 8 * 4 * 1024;
-constexpr int PACKED_FLOATS = OFF_TDIR + SZ_TDIR;
+constexpr int OFF_TFINAL = OFF_TDIR + SZ_TDIR;
+constexpr int OFF_T8 = OFF_TFINAL + SZ_HID;
+constexpr int OFF_T7 = OFF_T8 + SZ_HID;
+constexpr int OFF_T6 = OFF_T7 + SZ_HID;
+constexpr int OFF_T5 = OFF_T6 + SZ_HID;
+constexpr int OFF_T4 = OFF_T5 + SZ_HID;
+constexpr int OFF_T3 = OFF_T4 + SZ_HID;
+constexpr int OFF_T2 = OFF_T3 + SZ_HID;
+// the stream prefetches two 16 KiB stages past the layer it is in: readable tail behind the last image
+constexpr int STREAM_TAIL = 2 * 16 * 256;
+constexpr int PACKED_FLOATS = OFF_T2 + SZ_HID + STREAM_TAIL;
 
 // {param, out, in, seg0, seg1, JB, KB, off, t_col0, t_KBO, t_off}
 constexpr LayerDesc LAYERS[NL_FWD] = {

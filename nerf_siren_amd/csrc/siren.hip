@@ -22,7 +22,8 @@ constexpr int SOFF_W_SIGMA = SOFF_BIAS + 9 * 256;   // 256
 constexpr int SOFF_B_SIGMA = SOFF_W_SIGMA + 256;    // 1 (+3)
 constexpr int SOFF_W_RGB = SOFF_B_SIGMA + 4;        // 3 x 256
 constexpr int SOFF_B_RGB = SOFF_W_RGB + 768;        // 3 (+1)
-constexpr int SIREN_PACKED_FLOATS = SOFF_B_RGB + 4;
+// readable tail: the weight stream prefetches two stages past the color layer (mlp_core.h layer_mfma_lds)
+constexpr int SIREN_PACKED_FLOATS = SOFF_BIAS + (SOFF_B_RGB + 4 - SOFF_BIAS > 2 * GS * 256 ? SOFF_B_RGB + 4 - SOFF_BIAS : 2 * GS * 256);
 constexpr int SIREN_N_PARAMS = 22;  // network.{0..7}.layer.{weight,bias}, final_layer.*, color_layer_sine.layer.*, color_layer_linear.0.*
 
 struct SirenParamPtrs {
@@ -113,11 +114,13 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
     const int wid = threadIdx.x >> 6;
     const float *bias = packed + SOFF_BIAS + 4 * half;
     f32x16 h[8], acc[8];
-    layer_mfma_lds<1, 0, 8>(packed + SOFF_L1, bias, e, nullptr, acc, no_pre, film_epi(0), wlds, wid, lane);
+    WeightStage ws;
+    // ring phases: network.0 is 2 stages, every hidden layer 16, so the hidden and color layers start at phase 2
+    layer_mfma_lds<1, 0, 8, 0, true>(packed + SOFF_L1, bias, e, nullptr, acc, no_pre, film_epi(0), wlds, ws, wid, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) h[b] = acc[b];
     for (int l = 1; l < 8; ++l) {
-        layer_mfma_lds<8, 0, 8>(packed + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, film_epi(l), wlds, wid, lane);
+        layer_mfma_lds<8, 0, 8, 2, false>(packed + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, film_epi(l), wlds, ws, wid, lane);
 #pragma unroll
         for (int b = 0; b < 8; ++b) h[b] = acc[b];
     }
@@ -126,7 +129,7 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
         if (ok && half == 0) out[p] = sigma;
         return;
     }
-    layer_mfma_lds<1, 8, 8>(packed + SOFF_COLOR, bias + 256 * 8, de, h, acc, no_pre, film_epi(8), wlds, wid, lane);            // nerf.py:213
+    layer_mfma_lds<1, 8, 8, 2, false>(packed + SOFF_COLOR, bias + 256 * 8, de, h, acc, no_pre, film_epi(8), wlds, ws, wid, lane);            // nerf.py:213
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

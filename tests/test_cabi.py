@@ -34,7 +34,7 @@ def test_header_symbols_exported(libpath):
     lib.nerfmi_version.restype = ctypes.c_int
     assert lib.nerfmi_version() >= 100               # no GPU needed
     lib.nerfmi_nerf_packed_floats.restype = ctypes.c_size_t
-    assert lib.nerfmi_nerf_packed_floats() == 1154056   # csrc/mlp_layout.h PACKED_FLOATS
+    assert lib.nerfmi_nerf_packed_floats() == 1162248   # csrc/mlp_layout.h PACKED_FLOATS
 
 
 def test_argument_validation_without_gpu(libpath):

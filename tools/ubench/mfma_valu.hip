@@ -1,0 +1,74 @@
+// Microbenchmark: what does vector work placed between dependent MFMAs cost?  One wave per SIMD, a chain of
+// v_mfma_f32_32x32x2_f32 on one accumulator with V independent VALU instructions of a given kind after each.
+// Build: hipcc --offload-arch=gfx950 -O3 mfma_valu.hip -o mfma_valu
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KIND, int V, int CHAINS = 1>
+__global__ void __launch_bounds__(256) k(float *out, unsigned long long *ts, int iters) {
+    f32x16 c, c2;
+    for (int r = 0; r < 16; ++r) c[r] = 0.f, c2[r] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    float x[16];
+    for (int i = 0; i < 16; ++i) x[i] = a + i;
+    f32x4 av = {a, a, a, a}, bv = {b, b, b, b};
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (CHAINS >= 3) {
+                if (CHAINS == 3 || (u & 1) == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c2) : "v"(av), "v"(bv));
+            } else if (CHAINS == 1 || (u & 1) == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c2) : "v"(a), "v"(b));
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                float &y = x[(u * V + v) % 16];
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(y) : "v"(b));
+                if (KIND == 1) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(y));
+                if (KIND == 2) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(y) : "v"(b), "s"(__builtin_amdgcn_read_exec()));
+                if (KIND == 3) asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(y) : "v"(b));
+                if (KIND == 5) asm volatile("s_nop 0");
+                if (KIND == 6) asm volatile("s_add_u32 %0, %0, 1" : "+s"(it));
+                if (KIND == 4) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*reinterpret_cast<double *>(&x[2 * ((u * V + v) % 8)])) : "v"(*reinterpret_cast<double *>(&x[0])));
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+    for (int r = 0; r < 16; ++r) s += c[r] + c2[r] + x[r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) ts[0] = t1 - t0;
+}
+
+template <int KIND, int V, int CHAINS = 1>
+void run(const char *name) {
+    const int iters = 1000;
+    float *out; unsigned long long *ts, h;
+    (void)hipMalloc(&out, 256 * 256 * 4); (void)hipMalloc(&ts, 8);
+    hipLaunchKernelGGL((k<KIND, V, CHAINS>), dim3(256), dim3(256), 0, 0, out, ts, iters);
+    (void)hipDeviceSynchronize();
+    hipLaunchKernelGGL((k<KIND, V, CHAINS>), dim3(256), dim3(256), 0, 0, out, ts, iters);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(&h, ts, 8, hipMemcpyDeviceToHost);
+    printf("%-14s V=%2d  ticks per MFMA(+V) %.2f\n", name, V, h / (16.0 * iters));
+    (void)hipFree(out); (void)hipFree(ts);
+}
+template <int KIND> void sweep(const char *name) {
+    run<KIND, 0>(name); run<KIND, 2>(name); run<KIND, 4>(name); run<KIND, 8>(name); run<KIND, 12>(name); run<KIND, 16>(name); run<KIND, 24>(name);
+}
+int main() {
+    sweep<0>("v_fma_f32");
+    sweep<5>("s_nop 0");
+    printf("two independent chains, alternating:\n");
+    run<0, 0, 2>("v_fma_f32"); run<0, 2, 2>("v_fma_f32"); run<0, 4, 2>("v_fma_f32"); run<0, 8, 2>("v_fma_f32"); run<0, 12, 2>("v_fma_f32"); run<0, 16, 2>("v_fma_f32"); run<0, 24, 2>("v_fma_f32");
+    printf("bf16 32x32x16 MFMA, one dependent chain:\n");
+    run<0, 0, 3>("v_fma_f32"); run<0, 1, 3>("v_fma_f32"); run<0, 2, 3>("v_fma_f32"); run<0, 4, 3>("v_fma_f32"); run<0, 6, 3>("v_fma_f32"); run<0, 8, 3>("v_fma_f32"); run<0, 12, 3>("v_fma_f32");
+    printf("bf16 32x32x16 MFMA, two chains:\n");
+    run<0, 0, 4>("v_fma_f32"); run<0, 1, 4>("v_fma_f32"); run<0, 2, 4>("v_fma_f32"); run<0, 4, 4>("v_fma_f32"); run<0, 6, 4>("v_fma_f32"); run<0, 8, 4>("v_fma_f32"); run<0, 12, 4>("v_fma_f32");
+    printf("bf16, cvt_pk / dpp kinds, one chain:\n");
+    run<1, 2, 3>("v_mov_dpp"); run<1, 4, 3>("v_mov_dpp"); run<1, 6, 3>("v_mov_dpp"); run<4, 2, 3>("v_pk_add_f32"); run<4, 4, 3>("v_pk_add_f32"); run<4, 6, 3>("v_pk_add_f32");
+    return 0;
+}
