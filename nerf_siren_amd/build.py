@@ -36,7 +36,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc()] + FLAGS + srcs + ["-o", LIB + ".tmp"]
+    extra = os.environ.get("NERFMI_EXTRA_FLAGS", "").split()       # experiment builds (-D switches in csrc/)
+    cmd = [hipcc()] + FLAGS + extra + srcs + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

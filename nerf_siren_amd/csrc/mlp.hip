@@ -189,12 +189,14 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
     __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
     const int wid = threadIdx.x >> 6;
     const float *bias = packed + OFF_BIAS + 4 * half;
-    f32x16 h[8], acc[8];
+    WeightStage ws;
+    // two activation buffers used alternately: a layer reads one and its epilogue writes the other, so a
+    // finished block goes accumulator -> ReLU -> next layer's operand with no copy in between (fp32 MFMAs
+    // do not overlap with the wave's own vector instructions -- tools/ubench/mfma_valu.hip -- so every
+    // register move between layers is paid in matrix-pipe time)
+    f32x16 hA[8], hB[8];
     NERFMI_TS(1);
 
-    // Stores share the in-order vmcnt queue with the weight loads: a wait for a weight fragment issued
-    // after a store also waits for that store's acknowledgement, so the training variant keeps more
-    // fragments in flight.
     auto no_pre = [](int) { return 0; };
     // ReLU epilogue; in training each finished block goes straight to the tile-major image
     unsigned mk[4] = {0u, 0u, 0u, 0u};
@@ -208,44 +210,35 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
             return c;
         };
     };
-    auto copy8 = [&]() {
-#pragma unroll
-        for (int b = 0; b < 8; ++b) h[b] = acc[b];
+    // xyz_encoding_l (l = 2..8 except 5): 256 -> 256 + ReLU  (nerf.py:62-70)
+    auto hidden = [&](int l, const f32x16 *in, f32x16 *out_h) __attribute__((always_inline)) {
+        layer_mfma_lds<8, 0, 8, 0, false>(packed + LAYERS[l - 1].off, bias + 256 * (l - 1), in, nullptr, out_h, no_pre,
+                                          relu_epi(S_H + 256 * (l - 1)), wlds, ws, wid, lane);
+        if (SAVE) store_mask(S, l - 1, mk);
+        NERFMI_TS(1 + l);
     };
 
-    WeightStage ws;
-    layer_mfma_lds<2, 0, 8, 0, true>(packed + OFF_L1, bias, e, nullptr, acc, no_pre, relu_epi(S_H), wlds, ws, wid, lane);
+    layer_mfma_lds<2, 0, 8, 0, true>(packed + OFF_L1, bias, e, nullptr, hA, no_pre, relu_epi(S_H), wlds, ws, wid, lane);
     if (SAVE) store_mask(S, 0, mk);
-    copy8();
     NERFMI_TS(2);
-    for (int l = 1; l <= 3; ++l) {
-        layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, relu_epi(S_H + 256 * l), wlds, ws, wid, lane);
-        if (SAVE) store_mask(S, l, mk);
-        copy8();
-        NERFMI_TS(2 + l);
-    }
-    layer_mfma_lds<2, 8, 8, 0, false>(packed + OFF_L5, bias + 256 * 4, e, h, acc, no_pre, relu_epi(S_H + 256 * 4), wlds, ws, wid, lane);
+    hidden(2, hA, hB);
+    hidden(3, hB, hA);
+    hidden(4, hA, hB);
+    // xyz_encoding_5 on [xyz embedding | h4]  (skip connection, nerf.py:108-109)
+    layer_mfma_lds<2, 8, 8, 0, false>(packed + OFF_L5, bias + 256 * 4, e, hB, hA, no_pre, relu_epi(S_H + 256 * 4), wlds, ws, wid, lane);
     if (SAVE) store_mask(S, 4, mk);
-    copy8();
     NERFMI_TS(6);
-
-    for (int l = 5; l <= 7; ++l) {   // xyz_encoding_6..8
-        layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_L6 + (l - 5) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre,
-                                          relu_epi(S_H + 256 * l), wlds, ws, wid, lane);
-        if (SAVE) store_mask(S, l, mk);
-        copy8();
-        NERFMI_TS(2 + l);
-    }
-    const float sigma = dot_blocks<8>(h, packed + OFF_W_SIGMA + 4 * half) + packed[OFF_B_SIGMA];   // nerf.py:112
+    hidden(6, hA, hB);
+    hidden(7, hB, hA);
+    hidden(8, hA, hB);
+    const float sigma = dot_blocks<8>(hB, packed + OFF_W_SIGMA + 4 * half) + packed[OFF_B_SIGMA];   // nerf.py:112
     if (!SIGMA_ONLY) {
-        // xyz_encoding_final: no activation (nerf.py:116).  A call of its own rather than a fourth trip of the
-        // loop above: a run-time "last layer" flag inside the epilogue would put a branch around every slice
-        layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_FINAL, bias + 256 * 8, h, nullptr, acc, no_pre,
+        // xyz_encoding_final: no activation (nerf.py:116)
+        layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_FINAL, bias + 256 * 8, hB, nullptr, hA, no_pre,
                                           [&S](int jb, int q, f32x4 c, int) {
                                               if (SAVE) store_slice(S, S_FINAL + 32 * jb, q, c);
                                               return c;
                                           }, wlds, ws, wid, lane);
-        copy8();
         NERFMI_TS(10);
     }
     if (SIGMA_ONLY) {
@@ -253,7 +246,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         return;
     }
     f32x16 dh[4];
-    layer_mfma_lds<8, 1, 4, 0, false>(packed + OFF_DIR, packed + OFF_BIAS_DIR + 4 * half, h, de, dh, no_pre, relu_epi(S_DIRH), wlds, ws, wid, lane);
+    layer_mfma_lds<8, 1, 4, 0, false>(packed + OFF_DIR, packed + OFF_BIAS_DIR + 4 * half, hA, de, dh, no_pre, relu_epi(S_DIRH), wlds, ws, wid, lane);
     if (SAVE) store_mask(S, 8, mk);
     NERFMI_TS(11);
     float rgb[3];

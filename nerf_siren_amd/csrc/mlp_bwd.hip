@@ -60,7 +60,8 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
     }
     const float dsig = go.w;
 
-    f32x16 dz[8], acc[8];
+    // two gradient buffers used alternately (a layer reads one, its epilogue writes the other: no copies)
+    f32x16 dzA[8], dzB[8];
     unsigned mk[4];
     // d dir_h = W_rgb^T d pre, masked by the saved ReLU sign bits  (nerf.py:119-120)
     load_mask(S, 8, mk);
@@ -75,52 +76,54 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float s = __builtin_fmaf(w[2][t], dpre[2], __builtin_fmaf(w[1][t], dpre[1], w[0][t] * dpre[0]));
-                v[4 * q + t] = mask_bit(mk, b, q, t) ? s : 0.f;
+                v[4 * q + t] = mask_keep(mk, b, q, t, s);
             }
         }
-        dz[b] = v;
+        dzA[b] = v;
         store_block(Wk, W_DDIR + 32 * b, v);
     }
     __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
     const int wid = threadIdx.x >> 6;
-    // d final = W_dir[:, :256]^T dZ_dir                          (nerf.py:116-118; no activation on final)
     WeightStage ws;
-    layer_mfma_lds<4, 0, 8, 0, true>(packed + OFF_TDIR, nullptr, dz, nullptr, acc, [](int) { return 0; },
+    auto zero_pre = [](int) { return 0; };
+    // d final = W_dir[:, :256]^T dZ_dir                          (nerf.py:116-118; no activation on final)
+    layer_mfma_lds<4, 0, 8, 0, true>(packed + OFF_TDIR, nullptr, dzA, nullptr, dzB, zero_pre,
                             [&Wk](int jb, int q, f32x4 c, int) {
                                 store_slice(Wk, W_DFINAL + 32 * jb, q, c);
                                 return c;
                             }, wlds, ws, wid, lane);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) dz[b] = acc[b];
     // d h8 = W_final^T d final + w_sigma d sigma, masked by h8 > 0 (nerf.py:112-116)
     load_mask(S, 7, mk);
-    layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_TFINAL, nullptr, dz, nullptr, acc, [](int) { return 0; },
+    layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_TFINAL, nullptr, dzB, nullptr, dzA, zero_pre,
                              [&](int jb, int q, f32x4 c, int) {
                                  const f32x4 w = ldg4(packed + OFF_W_SIGMA + 32 * jb + 8 * q + 4 * half);
 #pragma unroll
                                  for (int t = 0; t < 4; ++t) {
                                      const float v = __builtin_fmaf(w[t], dsig, c[t]);
-                                     c[t] = mask_bit(mk, jb, q, t) ? v : 0.f;
+                                     c[t] = mask_keep(mk, jb, q, t, v);
                                  }
                                  store_slice(Wk, W_DZ + 7 * 256 + 32 * jb, q, c);
                                  return c;
                              }, wlds, ws, wid, lane);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) dz[b] = acc[b];
     // xyz_encoding_8 .. xyz_encoding_2: d h_{l-1} = W_l[:, hidden]^T dZ_l, masked by h_{l-1} > 0
-    for (int li = 7; li >= 1; --li) {
+    auto back = [&](int li, const f32x16 *in, f32x16 *out_dz) __attribute__((always_inline)) {
         const int wrow = W_DZ + (li - 1) * 256;
         load_mask(S, li - 1, mk);
-        layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_T8 + (7 - li) * SZ_HID, nullptr, dz, nullptr, acc, [](int) { return 0; },
+        layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_T8 + (7 - li) * SZ_HID, nullptr, in, nullptr, out_dz, zero_pre,
                                  [&](int jb, int q, f32x4 c, int) {
 #pragma unroll
-                                     for (int t = 0; t < 4; ++t) c[t] = mask_bit(mk, jb, q, t) ? c[t] : 0.f;
+                                     for (int t = 0; t < 4; ++t) c[t] = mask_keep(mk, jb, q, t, c[t]);
                                      store_slice(Wk, wrow + 32 * jb, q, c);
                                      return c;
                                  }, wlds, ws, wid, lane);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) dz[b] = acc[b];
-    }
+    };
+    back(7, dzA, dzB);
+    back(6, dzB, dzA);
+    back(5, dzA, dzB);
+    back(4, dzB, dzA);
+    back(3, dzA, dzB);
+    back(2, dzB, dzA);
+    back(1, dzA, dzB);
 }
 
 // ---------------------------------------------------------------------------
@@ -156,28 +159,27 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
                                         float *lds) {
     constexpr int JB = JW * WJ, KB = KW * WK;
     constexpr int ROWS = (JB + KB) * 32;
-    constexpr int NLD = ROWS / 32;            // float4 staging registers per thread
+    constexpr int NLD = JB + KB;              // staging slots per thread: slot i = rows 32i..32i+31 (A blocks, then B)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
     const int wj = wid / WK, wk = wid % WK;
     const int64_t tiles = ld / 32;
     const int64_t t_lo = tiles * chunk / T.chunks, t_hi = tiles * (chunk + 1) / T.chunks;
 
-    // global sources of this thread's staging slots: inside a tile the rows of an image are contiguous
-    // (128 B each), so slot u = row*8 + c4 is simply float4 number u of the row range: 1 KiB per wave-load
-    const float *src[NLD];
-    bool valid[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int u = i * 256 + tid, row = u >> 3, c4 = u & 7;
-        if (row < JB * 32) {
-            valid[i] = row < T.a_valid;
-            src[i] = work + (int64_t)(T.a_row0 + (valid[i] ? row : 0)) * 32 + 4 * c4;
-        } else {
-            const int rb = row - JB * 32;
-            valid[i] = rb < T.b_valid;
-            src[i] = saved + (int64_t)(T.b_row0 + (valid[i] ? rb : 0)) * 32 + 4 * c4;
-        }
-    }
+    // Inside a tile the rows of an image are contiguous (128 B each): thread (srow, c4) of slot i fetches float4
+    // c4 of row 32i + srow, so one wave-load is 1 KiB contiguous.  The per-thread part of every address (global
+    // and LDS) is the SAME for all slots and all tiles; the slot and tile parts are wave-uniform and live in
+    // scalar registers / immediate offsets.  That matters because fp32 MFMAs do not overlap with the wave's own
+    // vector instructions (tools/ubench/mfma_valu.hip): address arithmetic in the loop is paid in matrix-pipe time.
+    // Rows past the real operand (the 3 + 1 rows of the heads' dZ) are read as whatever follows them in the image
+    // -- at worst the dump tile behind the last real one (mlp_core.h RowImage): an MFMA output row depends on its own
+    // A row only, and the reduce kernel never reads the slab rows >= a_valid.  The padded B rows (row 63 of the
+    // xyz embedding, 27..31 of the direction embedding) are stored as zeros by the forward.
+    const int srow = tid >> 3, c4 = tid & 7;
+    const unsigned voff = (unsigned)(srow * 32 + 4 * c4);             // floats, global
+    const unsigned loff = (unsigned)(srow * LROW + 4 * c4);           // floats, LDS
+    const float *abase = work + (int64_t)T.a_row0 * 32;
+    const float *bbase = saved + (int64_t)T.b_row0 * 32;
+
     f32x16 acc[JW][KW];
 #pragma unroll
     for (int a = 0; a < JW; ++a)
@@ -190,55 +192,43 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
     for (int a = 0; a < JW; ++a) bsum[a] = 0.f;
 
     f32x4 stage[NLD];
-    auto load_tile = [&](int64_t t) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const bool is_a = (i * 256 + tid) < JB * 32 * 8;
-#ifdef DW_EXP_NOLOAD
-            stage[i] = ldg4(src[i] + t_lo * (is_a ? W_ROWS * 32 : SAVED_ROWS * 32));
-#else
-            stage[i] = ldg4(src[i] + t * (is_a ? W_ROWS * 32 : SAVED_ROWS * 32));   // consumed one tile later
-#endif
-        }
+    auto load_slot = [&](int i, int64_t t) {
+        const float *src = (i < JB) ? abase + t * (int64_t)(W_ROWS * 32) + i * 1024
+                                    : bbase + t * (int64_t)(SAVED_ROWS * 32) + (i - JB) * 1024;     // wave-uniform
+        stage[i] = ldg4(src + voff);
     };
-    auto write_tile = [&](float *buf) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int u = i * 256 + tid, row = u >> 3, c4 = u & 7;
-            // rows beyond the real operand (padding of the heads) are zeroed here, not at load time, so
-            // that the loads stay in flight under the previous tile's MFMAs
-            *reinterpret_cast<f32x4 *>(buf + row * LROW + 4 * c4) = valid[i] ? stage[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    auto write_slot = [&](int i, float *buf) {
+        *reinterpret_cast<f32x4 *>(buf + i * (32 * LROW) + loff) = stage[i];
     };
     // Double-buffered LDS, ONE barrier per tile: at the top of iteration t the registers hold tile t+1
     // (loaded during iteration t-1); it is written into the other buffer (last read in iteration t-1, which
     // every wave left through the barrier), tile t+2's loads are issued, then tile t is consumed.
     float *buf0 = lds, *buf1 = lds + ROWS * LROW;
     if (t_lo < t_hi) {
-        load_tile(t_lo);
-        write_tile(buf0);
-        if (t_lo + 1 < t_hi) load_tile(t_lo + 1);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) load_slot(i, t_lo);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) write_slot(i, buf0);
+        if (t_lo + 1 < t_hi) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) load_slot(i, t_lo + 1);
+        }
     }
     __syncthreads();
-    for (int64_t t = t_lo; t < t_hi; ++t) {
-        const bool odd = ((t - t_lo) & 1) != 0;
-        const float *cur = odd ? buf1 : buf0;
-        float *nxt = odd ? buf0 : buf1;
-        // The staging work for the following tiles is spread over this tile's MFMA stream instead of sitting
-        // in front of it (a wave issues in order: a block of 16 ds_write_b128 + 16 global loads ahead of the
-        // first ds_read would leave the matrix pipe idle for ~3k cycles per tile): slot i of tile t+1 is written
-        // to the other LDS buffer, and its register reloaded for tile t+2, after MFMA group i*(groups/NLD).
-        // Past the end the (clamped) tile is staged redundantly, which keeps the loop branch-free.
+    // one tile: consume `cur`, stage tile t+1 into `nxt` and reload the registers with tile t+2 -- the staging of
+    // slot i sits after MFMA group i*(groups/NLD), spread over the tile's MFMA stream instead of in front of it.
+    // Past the end the (clamped) tile is staged redundantly, which keeps the body branch-free.
+    auto tile = [&](int64_t t, const float *cur, float *nxt) __attribute__((always_inline)) {
         const int64_t t2 = (t + 2 < t_hi) ? t + 2 : t_hi - 1;
+        const float *arow = cur + (32 * (wj * JW) + (lane & 31)) * LROW + 4 * half;
+        const float *brow = cur + (32 * (JB + wk * KW) + (lane & 31)) * LROW + 4 * half;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 a[JW], b[KW];
 #pragma unroll
-            for (int x = 0; x < JW; ++x)
-                a[x] = *reinterpret_cast<const f32x4 *>(cur + (32 * (wj * JW + x) + (lane & 31)) * LROW + 8 * q + 4 * half);
+            for (int x = 0; x < JW; ++x) a[x] = *reinterpret_cast<const f32x4 *>(arow + x * (32 * LROW) + 8 * q);
 #pragma unroll
-            for (int x = 0; x < KW; ++x)
-                b[x] = *reinterpret_cast<const f32x4 *>(cur + (32 * (JB + wk * KW + x) + (lane & 31)) * LROW + 8 * q + 4 * half);
+            for (int x = 0; x < KW; ++x) b[x] = *reinterpret_cast<const f32x4 *>(brow + x * (32 * LROW) + 8 * q);
 #pragma unroll
             for (int x = 0; x < JW; ++x) bsum[x] += (a[x][0] + a[x][1]) + (a[x][2] + a[x][3]);
 #pragma unroll
@@ -248,22 +238,22 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
                         acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x][s], b[y][s], acc[x][y], 0, 0, 0);
-                    // staging slots interleaved with the MFMA groups
                     constexpr int NG = 4 * JW * KW;                       // MFMA groups per tile
                     const int gidx = (q * JW + x) * KW + y;
 #pragma unroll
-                    for (int i = 0; i < NLD; ++i) {
+                    for (int i = 0; i < NLD; ++i)
                         if (gidx == (i * NG) / NLD) {
-                            const int u = i * 256 + tid, row = u >> 3, c4 = u & 7;
-                            *reinterpret_cast<f32x4 *>(nxt + row * LROW + 4 * c4) =
-                                valid[i] ? stage[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-                            const bool is_a = (i * 256 + tid) < JB * 32 * 8;
-                            stage[i] = ldg4(src[i] + t2 * (is_a ? W_ROWS * 32 : SAVED_ROWS * 32));
+                            write_slot(i, nxt);
+                            load_slot(i, t2);
                         }
-                    }
                 }
         }
         __syncthreads();
+    };
+    // two tiles per trip, so that which buffer is read and which is written is static inside the body
+    for (int64_t t = t_lo; t < t_hi; t += 2) {
+        tile(t, buf0, buf1);
+        if (t + 1 < t_hi) tile(t + 1, buf1, buf0);
     }
     // partial slab [chunk][32*JB][32*KB] then bias slab [chunk][32*JB]
     float *slab = partial + T.part_off + (int64_t)chunk * (JB * 32 * (KB * 32 + 1));

@@ -10,7 +10,6 @@ namespace nerfmi {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PF_DEFAULT = 6;  // weight-fragment groups (1 KiB each) in flight per wave
 
 __device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
@@ -40,68 +39,17 @@ __device__ __forceinline__ float sin_cw(float x) {
     return s;
 }
 
-// out[jb] = epi(bias + W[jb-block rows] . [in0 ; in1])      (JB x (KB0+KB1) blocks)
-//   wp   : this layer's packed image + lane*4 (mlp_layout.h), streamed through a PF-deep register ring
+// layer contract (layer_mfma_lds below):  out[jb] = epi(bias + W[jb-block rows] . [in0 ; in1])   (JB x (KB0+KB1) blocks)
 //   bias : natural order + 4*half, or nullptr for a zero start (backward)
-//   pre  : called when a block STARTS; whatever it loads (e.g. the saved activations a backward block is
-//          masked with) is in flight under the block's MFMAs and handed to epi
+//   pre  : called when a block STARTS; whatever it loads is in flight under the block's MFMAs and handed to epi
 //   epi  : per-block epilogue (ReLU / mask / stores) in four slices: epi(jb, q, v, pv) receives registers
-//          4q..4q+3 of block jb (units 8q + 4*half + {0..3}) and returns their final values.
-// A wave issues in order and consecutive MFMAs of a block depend on each other through the accumulator,
-// so a VALU-heavy epilogue placed after a block would leave the matrix pipe idle.  The slices of block
-// jb-1 are therefore placed between the MFMA groups of block jb (software pipelining in source order):
-// each slice's VALU/memory work issues in the shadow of a 64-cycle MFMA.
-template <int KB0, int KB1, int JB, int PF = PF_DEFAULT, class Pre, class Epi>
-__device__ __forceinline__ void layer_mfma(const float *__restrict__ wp, const float *__restrict__ bias,
-                                           const f32x16 *in0, const f32x16 *in1, f32x16 *out, Pre pre, Epi epi) {
-    constexpr int KBT = KB0 + KB1;
-    constexpr int G = JB * KBT * 4;
-    f32x4 ring[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) ring[i] = ldg4(wp + i * 256);
-    f32x16 c_prev;
-    decltype(pre(0)) pv_prev = pre(0);
-    auto run_slice = [&](int jb, int q, const f32x16 &c, decltype(pre(0)) pv) {
-        const f32x4 o = epi(jb, q, f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}, pv);
-        out[jb][4 * q] = o[0]; out[jb][4 * q + 1] = o[1]; out[jb][4 * q + 2] = o[2]; out[jb][4 * q + 3] = o[3];
-    };
-#pragma unroll
-    for (int jb = 0; jb < JB; ++jb) {
-        auto pv = (jb == 0) ? pv_prev : pre(jb);
-        f32x16 c;
-        if (bias) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b = ldg4(bias + 32 * jb + 8 * q);
-                c[4 * q + 0] = b[0]; c[4 * q + 1] = b[1]; c[4 * q + 2] = b[2]; c[4 * q + 3] = b[3];
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = 0.f;
-        }
-#pragma unroll
-        for (int kb = 0; kb < KBT; ++kb) {
-            const f32x16 B = (kb < KB0) ? in0[kb] : in1[kb - KB0];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int g = (jb * KBT + kb) * 4 + q;
-                const f32x4 a = ring[g % PF];
-                if (g + PF < G) ring[g % PF] = ldg4(wp + (g + PF) * 256);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], B[4 * q + 0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], B[4 * q + 1], c, 0, 0, 0);
-                // previous block's epilogue slice, in the shadow of this block's MFMAs
-                const int gl = kb * 4 + q;
-                if (jb > 0 && gl % KBT == KBT / 2) run_slice(jb - 1, gl / KBT, c_prev, pv_prev);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], B[4 * q + 2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], B[4 * q + 3], c, 0, 0, 0);
-            }
-        }
-        c_prev = c;
-        pv_prev = pv;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) run_slice(JB - 1, q, c_prev, pv_prev);
-}
+//          4q..4q+3 of block jb (units 8q + 4*half + {0..3}) and returns their final values, which go to `out`
+//          (`out` must not alias the inputs: callers alternate two activation buffers).
+// The slices of block jb-1 are placed between the MFMA groups of block jb, so their stores and loads are spread
+// over the block instead of queueing up at its end.  Their VECTOR instructions are not free there: on gfx950 a
+// wave's fp32 MFMAs do not overlap with its own VALU work (tools/ubench/mfma_valu.hip: 64 + 13 + 4.5 cycles per
+// instruction for an MFMA followed by V vector instructions, against 32-cycle bf16 MFMAs that hide ~5), so the
+// epilogues are written for minimum instruction count.
 
 // ---------------------------------------------------------------------------------------------------
 // layer_mfma_lds: the same layer with the weight stream shared by the workgroup's four waves through LDS.
@@ -225,35 +173,12 @@ __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, 
 // element (row, point p) lives at base[((p/32)*ROWS + row)*32 + p%32].  A wave owns exactly one 32-point
 // tile, so everything it saves is one contiguous ROWS*128-byte region, and the dW GEMM later streams
 // 32-point tiles of whole row ranges (1 KiB per wave-load).
-// In the accumulator layout a lane holds, for ITS point, four consecutive units (registers 4q..4q+3);
-// a 4x4 transpose inside each lane quad (DPP quad_perm, no LDS) turns that into four consecutive
-// POINTS of ONE unit, so a block is saved/loaded with four 16-byte accesses per lane that cover full
-// 128-byte lines (4x fewer memory instructions than dword accesses, no partial-line writes).
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-// x[t] of lane i (i = lane&3)  ->  x[t] = old x[i] of lane t   (an involution)
-__device__ __forceinline__ void quad_transpose(float (&x)[4], int lane) {
-    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
-    float y[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float p = dpp_quad<0xB1>(x[r ^ 1]);          // quad_perm [1,0,3,2]
-        y[r] = (((r & 1) != 0) == o1) ? x[r] : p;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float p = dpp_quad<0x4E>(y[r ^ 2]);          // quad_perm [2,3,0,1]
-        x[r] = (((r & 2) != 0) == o2) ? y[r] : p;
-    }
-}
-
+// In the accumulator layout a lane holds, for ITS point, four consecutive units (registers 4q..4q+3): a slice
+// is saved with four 4-byte stores, each covering two full 128-byte rows.
 struct RowImage {
     float *tile;         // base + tile*ROWS*32
     int lane;
-    unsigned lane_off;   // (4*half + (lane&3))*32 + 4*((lane&31)>>2): unit 4*half+(lane&3), points 4m..4m+3
-    bool ok;             // point < n_points (columns beyond n_points are written as 0)
+    bool ok;             // point < n_points
     bool live;           // the wave owns at least one real point
     // A wave past the end (it exists because the workgroup's waves share barriers) is pointed at the DUMP
     // tile, one spare tile behind the image's n_tiles real ones, so that the stores in the layers' epilogues
@@ -263,7 +188,6 @@ struct RowImage {
                                          bool live_) {
         tile = base + (live_ ? tile_idx : n_tiles) * (int64_t)(rows * 32);
         lane = lane_;
-        lane_off = (unsigned)((4 * (lane_ >> 5) + (lane_ & 3)) * 32 + 4 * ((lane_ & 31) >> 2));
         ok = ok_;
         live = live_;
     }
@@ -273,59 +197,44 @@ struct RowImage {
 
 // store registers 4q..4q+3 of a block (units row0 + 8q + 4*half + {0..3}, row0 = block's first row)
 __device__ __forceinline__ void store_slice(const RowImage &im, int row0, int q, f32x4 v) {
-    float x[4];
+    // columns past n_points of the last tile are stored as computed (from the clamped last point): the
+    // backward chain's dZ is exactly 0 there (its grad_out is), which is what keeps them out of dW
+    // Four 4-byte stores, each writing two full 128-byte rows (units 4*half + t of the slice, 32 points).  The
+    // alternative -- a 4x4 cross-lane transpose (16 DPP/select instructions) feeding one 16-byte store -- is
+    // slower here: fp32 MFMAs do not overlap with the wave's own vector instructions, so the transpose is paid
+    // in matrix-pipe time (measured: forward+save -1.7 %, backward chain -2 % with the plain stores).
+    // Non-temporal: streamed once and read back by a later kernel, so the activation stream should not displace
+    // the L2-resident weights.
+    float *dst = im.tile + (row0 + 8 * q + 4 * (im.lane >> 5)) * 32 + (im.lane & 31);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) x[t] = im.ok ? v[t] : 0.f;
-    quad_transpose(x, im.lane);
-    // streamed once, read back by a later kernel: non-temporal so the 1.3 GB activation stream does not
-    // displace the L2-resident weights
-#ifdef FX_NOSTORE
-    if (x[0] == 123.456f)
-#endif
-    __builtin_nontemporal_store(f32x4{x[0], x[1], x[2], x[3]},
-                                reinterpret_cast<f32x4 *>(im.tile + (row0 + 8 * q) * 32 + im.lane_off));
+    for (int t = 0; t < 4; ++t) __builtin_nontemporal_store(v[t], dst + 32 * t);
 }
 __device__ __forceinline__ void store_block(const RowImage &im, int row0, const f32x16 &v) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) store_slice(im, row0, q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
 }
 
-// issue the four 16-byte loads of a block now ...
-__device__ __forceinline__ f32x16 load_block_raw(const RowImage &im, int row0) {
-    f32x16 v;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 o = *reinterpret_cast<const f32x4 *>(im.tile + (row0 + 8 * q) * 32 + im.lane_off);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[4 * q + t] = o[t];
-    }
-    return v;
-}
-// ... and un-transpose slice q when it is needed
-__device__ __forceinline__ f32x4 finish_slice(const RowImage &im, const f32x16 &raw, int q) {
-    float x[4] = {raw[4 * q], raw[4 * q + 1], raw[4 * q + 2], raw[4 * q + 3]};
-    quad_transpose(x, im.lane);
-    return f32x4{x[0], x[1], x[2], x[3]};
-}
-__device__ __forceinline__ f32x16 load_block(const RowImage &im, int row0) {
-    const f32x16 raw = load_block_raw(im, row0);
-    f32x16 v;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 o = finish_slice(im, raw, q);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[4 * q + t] = o[t];
-    }
-    return v;
-}
-
 // ReLU sign bits of slice q of block jb into the per-layer mask words (mlp_layout.h S_MASK)
 __device__ __forceinline__ void mask_or(unsigned (&mk)[4], int jb, int q, const f32x4 &c) {
+    // v >= +0 after the ReLU, so (v > 0) == (bits != 0) == min(bits, 1): two instructions per value, written
+    // out because the compiler expands the C form into compare + select + or.  (Take the element into a
+    // scalar first: __builtin_bit_cast applied to a vector element expression is miscompiled by this hipcc.)
+    const int sh = 16 * (jb & 1) + 4 * q;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) mk[jb >> 1] |= (c[t] > 0.f ? 1u : 0u) << (16 * (jb & 1) + 4 * q + t);
+    for (int t = 0; t < 4; ++t) {
+        const float v = c[t];
+        unsigned one;
+        asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(v));
+        asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(mk[jb >> 1]) : "v"(one), "s"(sh + t));
+    }
 }
 __device__ __forceinline__ bool mask_bit(const unsigned (&mk)[4], int jb, int q, int t) {
     return (mk[jb >> 1] >> (16 * (jb & 1) + 4 * q + t)) & 1u;
+}
+// v where the bit is set, +0 where it is not: sign-extend the one-bit field and AND (two instructions)
+__device__ __forceinline__ float mask_keep(const unsigned (&mk)[4], int jb, int q, int t, float v) {
+    const int m = __builtin_amdgcn_sbfe((int)mk[jb >> 1], 16 * (jb & 1) + 4 * q + t, 1);
+    return __int_as_float(__float_as_int(v) & m);
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_mask(const RowImage &im, int layer, unsigned (&mk)[4]) {
@@ -337,9 +246,14 @@ __device__ __forceinline__ void load_mask(const RowImage &im, int layer, unsigne
     mk[0] = v[0]; mk[1] = v[1]; mk[2] = v[2]; mk[3] = v[3];
 }
 
+// ReLU as a signed-integer max on the bit pattern (negative floats are negative integers, -0 -> +0): one
+// v_max_i32 where fmaxf costs a canonicalisation plus a v_max_f32
+__device__ __forceinline__ float relu1(float x) {
+    return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0));
+}
 __device__ __forceinline__ f32x4 relu4(f32x4 c) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c[r] = fmaxf(c[r], 0.f);
+    for (int r = 0; r < 4; ++r) c[r] = relu1(c[r]);
     return c;
 }
 
