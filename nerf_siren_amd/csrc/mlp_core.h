@@ -145,9 +145,13 @@ __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, 
             for (int q = 0; q < 4; ++q) {
                 const int g = (jb * KBT + kb) * 4 + q;
                 const int stage = g / GS, gl = g % GS;
-                if (gl == 0) {                                   // stage boundary (resolved at compile time)
-                    lwrite(stage + 1);
-                    gload(stage + 2);
+                // The stage's staging work is spread over its first groups, one piece per group: piece i of
+                // stage+1 goes to LDS and its register is reloaded with piece i of stage+2.  Issued back to back
+                // the four 1 KiB LDS writes (and loads) of all four waves queue on the LDS/TA pipes and the wave
+                // waits; one per MFMA group is absorbed (tools/ubench/mfma_valu.hip).
+                if (gl < QS) {
+                    *reinterpret_cast<f32x4 *>(ldst + (((stage + 1 + PH) % NSLOT) * GS + gl) * 256) = ws.st[gl];
+                    ws.st[gl] = ldg4(gsrc + ((stage + 2) * GS + gl) * 256);
                 }
                 if (gl == GS / 2) __syncthreads();
                 // fragments are read ONE group ahead (two register sets): the LDS latency of group g+1 hides
@@ -157,7 +161,14 @@ __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, 
                 c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], B[4 * q + 0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], B[4 * q + 1], c, 0, 0, 0);
                 const int gq = kb * 4 + q;
-                if (jb > 0 && gq % KBT == KBT / 2) run_slice(jb - 1, gq / KBT, c_prev, pv_prev);
+                if (jb > 0 && gq % KBT == KBT / 2) {
+                    // fenced: the scheduler would otherwise scatter the slice's vector instructions one by one
+                    // between the MFMAs, and each interruption of the fp32 MFMA stream costs ~13 cycles on top of
+                    // the instructions themselves (tools/ubench/mfma_valu.hip) -- one clump per slice is cheaper
+                    __builtin_amdgcn_sched_barrier(0);
+                    run_slice(jb - 1, gq / KBT, c_prev, pv_prev);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], B[4 * q + 2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], B[4 * q + 3], c, 0, 0, 0);
             }

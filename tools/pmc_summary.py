@@ -13,7 +13,7 @@ import sys
 
 def main(root, out):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(f"{root}/*/*/*counter_collection.csv"):
+    for f in glob.glob(f"{root}/*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "nerfmi" not in k:

@@ -14,6 +14,11 @@ __global__ void __launch_bounds__(256) k(float *out, unsigned long long *ts, int
     float x[16];
     for (int i = 0; i < 16; ++i) x[i] = a + i;
     f32x4 av = {a, a, a, a}, bv = {b, b, b, b};
+    __shared__ float lds[4096];
+    lds[threadIdx.x] = a;
+    f32x4 ld[4] = {av, av, av, av};
+    const unsigned laddr = (threadIdx.x & 63) * 16;
+    const float *gaddr = out + blockIdx.x * 256 + threadIdx.x;
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -31,6 +36,10 @@ __global__ void __launch_bounds__(256) k(float *out, unsigned long long *ts, int
                 if (KIND == 2) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(y) : "v"(b), "s"(__builtin_amdgcn_read_exec()));
                 if (KIND == 3) asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(y) : "v"(b));
                 if (KIND == 5) asm volatile("s_nop 0");
+                if (KIND == 7) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[(u * V + v) % 4]) : "v"(laddr));
+                if (KIND == 8) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[(u * V + v) % 4]) : "v"(gaddr));
+                if (KIND == 9) asm volatile("ds_write_b128 %0, %1" : : "v"(laddr), "v"(ld[0]));
+                if (KIND == 10) asm volatile("global_store_dword %0, %1, off" : : "v"(gaddr), "v"(y));
                 if (KIND == 6) asm volatile("s_add_u32 %0, %0, 1" : "+s"(it));
                 if (KIND == 4) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*reinterpret_cast<double *>(&x[2 * ((u * V + v) % 8)])) : "v"(*reinterpret_cast<double *>(&x[0])));
             }
@@ -38,7 +47,8 @@ __global__ void __launch_bounds__(256) k(float *out, unsigned long long *ts, int
     }
     unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0;
-    for (int r = 0; r < 16; ++r) s += c[r] + c2[r] + x[r];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+    for (int r = 0; r < 16; ++r) s += c[r] + c2[r] + x[r] + ld[r & 3][r >> 2];
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) ts[0] = t1 - t0;
 }
@@ -47,7 +57,7 @@ template <int KIND, int V, int CHAINS = 1>
 void run(const char *name) {
     const int iters = 1000;
     float *out; unsigned long long *ts, h;
-    (void)hipMalloc(&out, 256 * 256 * 4); (void)hipMalloc(&ts, 8);
+    (void)hipMalloc(&out, 256 * 256 * 4 * 4); (void)hipMalloc(&ts, 8);
     hipLaunchKernelGGL((k<KIND, V, CHAINS>), dim3(256), dim3(256), 0, 0, out, ts, iters);
     (void)hipDeviceSynchronize();
     hipLaunchKernelGGL((k<KIND, V, CHAINS>), dim3(256), dim3(256), 0, 0, out, ts, iters);
@@ -64,6 +74,16 @@ int main() {
     sweep<5>("s_nop 0");
     printf("two independent chains, alternating:\n");
     run<0, 0, 2>("v_fma_f32"); run<0, 2, 2>("v_fma_f32"); run<0, 4, 2>("v_fma_f32"); run<0, 8, 2>("v_fma_f32"); run<0, 12, 2>("v_fma_f32"); run<0, 16, 2>("v_fma_f32"); run<0, 24, 2>("v_fma_f32");
+    printf("fp32 MFMA chain + memory instructions:\n");
+    run<7, 1>("ds_read_b128"); run<7, 2>("ds_read_b128"); run<7, 4>("ds_read_b128");
+    run<8, 1>("global_load_x4"); run<8, 2>("global_load_x4"); run<8, 4>("global_load_x4");
+    run<9, 1>("ds_write_b128"); run<9, 2>("ds_write_b128"); run<9, 4>("ds_write_b128");
+    run<10, 1>("global_store_dw"); run<10, 2>("global_store_dw"); run<10, 4>("global_store_dw");
+    printf("bf16 MFMA chain + memory instructions:\n");
+    run<7, 1, 3>("ds_read_b128"); run<7, 2, 3>("ds_read_b128"); run<7, 3, 3>("ds_read_b128");
+    run<8, 1, 3>("global_load_x4"); run<8, 2, 3>("global_load_x4");
+    run<9, 1, 3>("ds_write_b128"); run<9, 2, 3>("ds_write_b128");
+    run<10, 1, 3>("global_store_dw"); run<10, 2, 3>("global_store_dw");
     printf("bf16 32x32x16 MFMA, one dependent chain:\n");
     run<0, 0, 3>("v_fma_f32"); run<0, 1, 3>("v_fma_f32"); run<0, 2, 3>("v_fma_f32"); run<0, 4, 3>("v_fma_f32"); run<0, 6, 3>("v_fma_f32"); run<0, 8, 3>("v_fma_f32"); run<0, 12, 3>("v_fma_f32");
     printf("bf16 32x32x16 MFMA, two chains:\n");
