@@ -44,6 +44,9 @@ def parse():
                     help="nerf = the reference's live 8x256 ReLU NeRF; siren = its FiLM-SIREN field (inference only)")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="fp32",
                     help="fp32 = exact fp32 MFMA (default); bf16x3 = opt-in split-bf16 inference math (--mode infer)")
+    ap.add_argument("--optimizer", choices=["fused", "torch"], default="fused",
+                    help="training: nerf_siren_amd.training.FusedAdam + FusedMSELoss (one launch each) or torch.optim.Adam "
+                         "+ elementwise loss -- same arithmetic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work in the bounded cpu_baseline sample")
     return ap.parse_args()
@@ -139,7 +142,13 @@ def main():
     train = args.mode == "train"
     if train:
         params = [p for m in models for p in m.parameters()]
-        opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8)       # utils/__init__.py:20, opt.py
+        from nerf_siren_amd.training import FusedAdam, FusedMSELoss
+        if args.optimizer == "fused":
+            opt = FusedAdam(models, lr=5e-4, eps=1e-8)           # utils/__init__.py:20 (Adam, eps 1e-8), one launch/model
+            loss_fn = FusedMSELoss(unit_grad=True)               # losses.py:10-20 + autograd, one launch
+        else:
+            opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8)
+            loss_fn = None
         reducer = FlatGradAllReduce(models, world)
 
     # ---- per-kernel timing of the dominant kernel (fine MLP forward) -------------------------
@@ -192,11 +201,18 @@ def main():
         if train:
             res = render_rays(models, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, True, False)
             t = tgt_pool[i % n_pool]
-            loss = ((res["rgb_coarse"] - t) ** 2).mean() + ((res["rgb_fine"] - t) ** 2).mean()   # losses.py:15-20
+            if loss_fn is not None:
+                loss = loss_fn(res, t)
+            else:
+                loss = ((res["rgb_coarse"] - t) ** 2).mean() + ((res["rgb_fine"] - t) ** 2).mean()   # losses.py:15-20
             opt.zero_grad(set_to_none=True)
             loss.backward()
-            reducer.all_reduce()
-            opt.step()
+            if loss_fn is not None:
+                reducer.all_reduce(average=False)               # the 1/world factor rides in the Adam kernel
+                opt.step(grad_scale=1.0 / world)
+            else:
+                reducer.all_reduce()
+                opt.step()
         else:
             with torch.no_grad():
                 render_rays(models, emb, rays, 64, False, 0, 0, 64, 1024 * 32, True, True)

@@ -162,6 +162,22 @@ int nerfmi_importance_resample(const float *z_coarse, const float *weights_coars
                                int n_samples, int n_importance, float *z_new_out, float *z_fine_out,
                                nerfmi_stream_t stream);
 
+/* ==== the step after the path in training ===========================================
+ * losses.py:10-20 MSELoss = nn.MSELoss(mean)(rgb_coarse, t) [+ nn.MSELoss(mean)(rgb_fine, t)], its autograd
+ * (d x = (2/n_elems) * (x - t) * grad_out) and metrics.py:4-13 psnr = -10 log10(mse), in one launch.
+ * rgb_coarse / rgb_fine / targets: n_elems floats ((n_rays,3) flattened); either prediction may be NULL.
+ * out4 = {loss, mse_coarse, mse_fine, psnr of the fine (else coarse) prediction}; grad_* optional (NULL = skip). */
+int nerfmi_mse_loss(const float *rgb_coarse, const float *rgb_fine, const float *targets, int64_t n_elems,
+                    float grad_out, float *out4, float *grad_coarse, float *grad_fine, nerfmi_stream_t stream);
+
+/* utils/__init__.py:20 -> torch.optim.Adam(params, lr, eps=1e-8, weight_decay) (torch/optim/adam.py
+ * _single_tensor_adam, amsgrad=False): one launch over a FLAT parameter buffer and its flat gradient/state.
+ * step = 1 for the first update.  grad is multiplied by grad_scale first (1/world_size after a summed
+ * all-reduce; 1 = off).  beta1 must be > 0.5 (torch's lerp formula switches below). */
+int nerfmi_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, int64_t step, double grad_scale,
+                     nerfmi_stream_t stream);
+
 /* ==== EG3D tri-plane importance renderer (forward) ========================================================
  * volumetric_rendering/renderer.py, ray_marcher.py, ray_sampler.py, math_utils.py; eg3d_training/triplane.py.
  * Planes are consumed channels-last: planes_hwc (n*3, H, W, 32), produced once per plane update from the

@@ -60,6 +60,9 @@ SIGNATURES = {
     "nerfmi_search_lerp": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _f]),
     "nerfmi_searchsorted": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "nerfmi_merge_sorted": (_i, [_f, _f, _i, _i, _i, _f, _f]),
+    "nerfmi_mse_loss": (_i, [_f, _f, _f, _i64, _fl, _f, _f, _f, _f]),
+    "nerfmi_adam_step": (_i, [_f, _f, _f, _f, _i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64,
+                             C.c_double, _f]),
     "nerfmi_importance_resample": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _f]),
 }
 

@@ -65,11 +65,15 @@ class NeRF(nn.Module):
         sd = dict(self.named_parameters())
         return [sd[k] for k in ops.PARAM_ORDER]
 
+    def mark_parameters_changed(self):
+        """Called by writers that change parameter memory without going through torch (training.FusedAdam)."""
+        self._epoch = getattr(self, "_epoch", 0) + 1
+
     def packed(self):
         """Fragment-order weight blob (csrc/mlp_layout.h), re-packed when any
         parameter changed (optimizer steps bump tensor._version)."""
         ps = self.param_list()
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        key = (getattr(self, "_epoch", 0),) + tuple((p.data_ptr(), p._version) for p in ps)
         if self._packed is None or key != self._packed_key or self._packed.device != ps[0].device:
             self._packed = ops.nerf_pack(ps, self._packed if (self._packed is not None
                                                                and self._packed.device == ps[0].device) else None)

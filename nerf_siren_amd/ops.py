@@ -239,9 +239,9 @@ def composite_backward(field, z, rays, noise, noise_std, white_back, g_rgb, g_de
     p = z.shape[1]
     field = _req(field.reshape(n, p, 4), "field")
     noise = _req(noise, "noise", (n, p)) if (noise is not None and noise_std != 0) else None
-    g_rgb = _req(g_rgb, "g_rgb", (n, 3))
-    g_depth = _req(g_depth, "g_depth", (n,))
-    g_opacity = _req(g_opacity, "g_opacity", (n,))
+    g_rgb = _req(g_rgb, "g_rgb", (n, 3)) if g_rgb is not None else None          # None = zero (NULL in the C ABI)
+    g_depth = _req(g_depth, "g_depth", (n,)) if g_depth is not None else None
+    g_opacity = _req(g_opacity, "g_opacity", (n,)) if g_opacity is not None else None
     grad_field = torch.empty((n * p, 4), device=rays.device, dtype=torch.float32)
     check(_lib.lib().nerfmi_composite_backward(ptr(field), ptr(z), ptr(rays), ptr(noise), float(noise_std), n, p,
                                                int(bool(white_back)), ptr(g_rgb), ptr(g_depth), ptr(g_opacity),
@@ -327,3 +327,34 @@ def importance_resample(z_coarse, weights_coarse, n_importance, u=None, want_new
     check(_lib.lib().nerfmi_importance_resample(ptr(z_coarse), ptr(weights_coarse), ptr(u), n, s, n_importance,
                                                 ptr(z_new), ptr(z_fine), _stream(z_coarse)), "importance_resample")
     return (z_fine, z_new) if want_new else z_fine
+
+
+# --------------------------------------------------------------------------- f2: loss + optimizer
+def mse_loss(rgb_coarse, rgb_fine, targets, grad_out=1.0, want_grads=True):
+    """losses.py:10-20 + its autograd + metrics.py psnr in one launch.
+    Returns (out4 = [loss, mse_coarse, mse_fine, psnr], grad_coarse or None, grad_fine or None)."""
+    targets = _req(targets, "targets")
+    n = targets.numel()
+    rc = _req(rgb_coarse, "rgb_coarse", tuple(targets.shape)) if rgb_coarse is not None else None
+    rf = _req(rgb_fine, "rgb_fine", tuple(targets.shape)) if rgb_fine is not None else None
+    if rc is None and rf is None:
+        raise ValueError("mse_loss needs rgb_coarse and/or rgb_fine")
+    out4 = torch.empty(4, device=targets.device, dtype=torch.float32)
+    gc = torch.empty_like(rc) if (want_grads and rc is not None) else None
+    gf = torch.empty_like(rf) if (want_grads and rf is not None) else None
+    check(_lib.lib().nerfmi_mse_loss(ptr(rc), ptr(rf), ptr(targets), n, float(grad_out), ptr(out4), ptr(gc), ptr(gf),
+                                     _stream(targets)), "mse_loss")
+    return out4, gc, gf
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+              grad_scale=1.0):
+    """torch.optim.Adam's update on flat fp32 buffers, in place (one launch)."""
+    n = param.numel()
+    for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        _req(t, name)
+        if t.numel() != n or not t.is_contiguous():
+            raise ValueError(f"adam_step: {name} must be a contiguous buffer of {n} floats")
+    check(_lib.lib().nerfmi_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), n, float(lr),
+                                      float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
+                                      float(grad_scale), _stream(param)), "adam_step")

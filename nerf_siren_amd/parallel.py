@@ -13,6 +13,23 @@ import torch
 import torch.distributed as dist
 
 
+def flat_grad_alias(params):
+    """If the gradients of `params` are consecutive slices of ONE allocation, in this order -- which is how the
+    HIP backward writes them (ops.flat_views) -- return a 1-D tensor aliasing that memory (no copy), else None.
+    (autograd hands p.grad over detached, so `._base` is not available: the storage and the offsets are compared.)"""
+    gs = [p.grad for p in params]
+    if not gs or any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in gs):
+        return None
+    st = gs[0].untyped_storage()
+    off = gs[0].storage_offset()
+    start = off
+    for g in gs:
+        if g.untyped_storage().data_ptr() != st.data_ptr() or g.storage_offset() != off:
+            return None
+        off += g.numel()
+    return torch.empty(0, device=gs[0].device, dtype=torch.float32).set_(st, start, (off - start,))
+
+
 class FlatGradAllReduce:
     """all-reduce(mean) of the models' gradients with as few collectives as storage allows.
 
@@ -32,12 +49,12 @@ class FlatGradAllReduce:
     def _bases(self):
         bases, loose = [], []
         for m in self.models:
-            ps = [p for p in m.parameters() if p.requires_grad and p.grad is not None]
+            ps = list(m.param_list()) if hasattr(m, "param_list") else list(m.parameters())
+            ps = [p for p in ps if p.requires_grad and p.grad is not None]
             if not ps:
                 continue
-            b = ps[0].grad._base
-            n = sum(p.grad.numel() for p in ps)
-            if b is not None and b.dim() == 1 and b.numel() == n and all(p.grad._base is b for p in ps):
+            b = flat_grad_alias(ps)
+            if b is not None:
                 bases.append(b)
             else:
                 loose.extend(ps)
@@ -47,17 +64,21 @@ class FlatGradAllReduce:
         for p in self.params:
             p.grad = None
 
-    def all_reduce(self):
-        """mean over ranks, in place (DDP semantics). Returns the reduced buffers."""
+    def all_reduce(self, average: bool = True):
+        """mean over ranks, in place (DDP semantics). Returns the reduced buffers.
+        average=False leaves the SUM in the buffers: the caller folds 1/world into the optimizer
+        (training.FusedAdam.step(grad_scale=1/world)) and saves a pass over the gradients."""
         bases, loose = self._bases()
         if self.world > 1:
             for b in bases:
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
-                b.mul_(1.0 / self.world)
+                if average:
+                    b.mul_(1.0 / self.world)
             if loose:
                 flat = torch.cat([p.grad.reshape(-1) for p in loose])
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-                flat.mul_(1.0 / self.world)
+                if average:
+                    flat.mul_(1.0 / self.world)
                 off = 0
                 for p in loose:
                     p.grad.copy_(flat[off:off + p.grad.numel()].view_as(p.grad))

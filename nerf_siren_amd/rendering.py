@@ -58,18 +58,17 @@ class FieldRender(torch.autograd.Function):
         ctx.save_for_backward(rays, z, noise if noise is not None else rays.new_empty(0), field, saved, packed)
         ctx.cfg = (noise is not None, float(noise_std), bool(white_back))
         ctx.mark_non_differentiable(weights)
+        ctx.set_materialize_grads(False)        # absent d/d(depth, opacity) arrive as None -> NULL in the C ABI
         return rgb, depth, opacity, weights
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_opacity, _g_w):
         rays, z, noise, field, saved, packed = ctx.saved_tensors
         has_noise, noise_std, white_back = ctx.cfg
-        n = rays.shape[0]
-        g_rgb = g_rgb if g_rgb is not None else rays.new_zeros((n, 3))
-        g_depth = g_depth if g_depth is not None else rays.new_zeros((n,))
-        g_opacity = g_opacity if g_opacity is not None else rays.new_zeros((n,))
+        if g_rgb is None and g_depth is None and g_opacity is None:
+            return (None,) * (6 + len(ops.PARAM_ORDER))
         grad_field = ops.composite_backward(field, z, rays, noise if has_noise else None, noise_std, white_back,
-                                            g_rgb.contiguous(), g_depth.contiguous(), g_opacity.contiguous())
+                                            g_rgb, g_depth, g_opacity)
         grads = ops.nerf_backward_rays(packed, rays, z, saved, grad_field)
         return (None, None, None, None, None, None, *grads)
 

@@ -36,7 +36,9 @@ class MSELoss(nn.Module):
         return loss
 
 
-loss_dict = {'mse': MSELoss}
+from .training import FusedAdam, FusedMSELoss  # noqa: E402
+
+loss_dict = {'mse': MSELoss, 'mse_fused': FusedMSELoss}
 
 
 def mse(image_pred, image_gt, valid_mask=None, reduction='mean'):
@@ -62,6 +64,8 @@ def get_optimizer(hparams, models):
         return torch.optim.SGD(parameters, lr=hparams.lr, momentum=hparams.momentum, weight_decay=hparams.weight_decay)
     if hparams.optimizer == 'adam':
         return torch.optim.Adam(parameters, lr=hparams.lr, eps=eps, weight_decay=hparams.weight_decay)
+    if hparams.optimizer == 'adam_fused':      # same update as 'adam', one launch per model (training.FusedAdam)
+        return FusedAdam(models, lr=hparams.lr, eps=eps, weight_decay=hparams.weight_decay)
     raise ValueError('optimizer not recognized! (sgd / adam; the reference\'s radam / ranger copies are host-side '
                      'code outside the path)')
 

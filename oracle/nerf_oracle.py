@@ -432,3 +432,44 @@ def siren_forward(p: dict, inp, frequencies, phase_shifts, ray_directions, sigma
     pre = (c @ p["color_layer_linear.0.weight"].T + p["color_layer_linear.0.bias"]).astype(F32)
     rgb = (F32(1) / (F32(1) + np.exp(-pre.astype(F64)))).astype(F32)
     return np.concatenate([rgb, sigma], -1).astype(F32)
+
+
+# ----------------------------------------------------------------------------
+# f2  the step after the path: losses.py:10-20 (MSELoss), metrics.py:4-13 (mse / psnr),
+#     utils/__init__.py:20 -> torch.optim.Adam (torch/optim/adam.py _single_tensor_adam, amsgrad=False)
+# ----------------------------------------------------------------------------
+def mse_loss(rgb_coarse, rgb_fine, targets, grad_out=1.0):
+    """-> dict(loss, mse_coarse, mse_fine, psnr, g_coarse, g_fine); either prediction may be None.
+    nn.MSELoss(mean): mean((x-t)^2) (fp64 accumulate here); backward (2/numel)*(x-t)*grad_out, fp32 op by op."""
+    t = np.asarray(targets, F32)
+    n = t.size
+    norm = F32(2.0 / n)
+    out = {"g_coarse": None, "g_fine": None, "mse_coarse": F32(0), "mse_fine": F32(0)}
+    for key, x in (("coarse", rgb_coarse), ("fine", rgb_fine)):
+        if x is None:
+            continue
+        d = (np.asarray(x, F32) - t).astype(F32)
+        out["mse_" + key] = F32((d * d).astype(F32).astype(F64).sum() / n)
+        out["g_" + key] = ((norm * d).astype(F32) * F32(grad_out)).astype(F32)
+    if rgb_coarse is not None and rgb_fine is not None:
+        out["loss"] = F32(out["mse_coarse"] + out["mse_fine"])
+    else:
+        out["loss"] = out["mse_coarse"] if rgb_coarse is not None else out["mse_fine"]
+    out["psnr"] = F32(-10.0) * np.log10(out["mse_fine"] if rgb_fine is not None else out["mse_coarse"], dtype=F32)
+    return out
+
+
+def adam_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """One torch.optim.Adam update of fp32 arrays; returns (p, m, v).  The Python-float scalars are formed in
+    double and rounded once, every tensor op is one fp32 rounding (torch fuses lerp's multiply-add: <= 1 ulp)."""
+    p, g, m, v = (np.asarray(a, F32) for a in (p, g, m, v))
+    b1, b2 = betas
+    if weight_decay != 0:
+        g = (g + (F32(weight_decay) * p).astype(F32)).astype(F32)
+    m = (m + (F32(1.0 - b1) * (g - m).astype(F32)).astype(F32)).astype(F32)
+    v = ((v * F32(b2)).astype(F32) + ((F32(1.0 - b2) * g).astype(F32) * g).astype(F32)).astype(F32)
+    step_size = lr / (1.0 - b1 ** step)
+    bc2_sqrt = (1.0 - b2 ** step) ** 0.5
+    denom = ((np.sqrt(v).astype(F32) / F32(bc2_sqrt)).astype(F32) + F32(eps)).astype(F32)
+    p = (p + ((F32(-step_size) * m).astype(F32) / denom).astype(F32)).astype(F32)
+    return p, m, v

@@ -605,8 +605,10 @@ def test_eg3d_ray_limits_box_and_auto(golden, dev, osg):
 
 
 # --------------------------------------------------------------------------- PSNR parity (metric: "+ PSNR")
-def test_psnr_parity(golden, dev):
-    """Teacher-scene protocol: the same 240 Adam steps the reference ran on CPU
+@pytest.mark.parametrize("impl", ["torch", "fused"])
+def test_psnr_parity(golden, dev, impl):
+    """impl: torch.optim.Adam + elementwise loss, or training.FusedAdam + FusedMSELoss (one launch each).
+    Teacher-scene protocol: the same 240 Adam steps the reference ran on CPU
     (tools/make_psnr_golden.py: same teacher images, same batches, same injected random draws, same
     initial weights, Adam lr 5e-4) on the HIP path; validation PSNR must agree within 0.1 dB (north_star)."""
     from nerf_siren_amd import Embedding, NeRF, render_rays
@@ -621,7 +623,13 @@ def test_psnr_parity(golden, dev):
     emb = [Embedding(3, 10), Embedding(3, 4)]
     rays, tgt = T(g["rays"], dev), T(g["target"], dev)
     val_rays, val_tgt = T(g["val_rays"], dev), T(g["val_target"], dev)
-    opt = torch.optim.Adam([p for m in ms for p in m.parameters()], lr=float(g["cfg_lr"]), eps=1e-8)
+    if impl == "fused":
+        from nerf_siren_amd.training import FusedAdam, FusedMSELoss
+        opt = FusedAdam(ms, lr=float(g["cfg_lr"]), eps=1e-8)
+        loss_fn = FusedMSELoss(unit_grad=True)
+    else:
+        opt = torch.optim.Adam([p for m in ms for p in m.parameters()], lr=float(g["cfg_lr"]), eps=1e-8)
+        loss_fn = None
     psnr = []
     for step in range(steps + 1):
         if step % every == 0:
@@ -634,7 +642,10 @@ def test_psnr_parity(golden, dev):
         rg = {k: T(v, dev) for k, v in synth.psnr_step_rng(step, B, S, F).items()}
         res = render_rays(ms, emb, rays[idx], S, False, 1.0, 0.0, F, 1 << 15, True, False, rng=rg)
         t = tgt[idx]
-        loss = ((res["rgb_coarse"] - t) ** 2).mean() + ((res["rgb_fine"] - t) ** 2).mean()
+        if loss_fn is not None:
+            loss = loss_fn(res, t)
+        else:
+            loss = ((res["rgb_coarse"] - t) ** 2).mean() + ((res["rgb_fine"] - t) ** 2).mean()
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -722,3 +733,112 @@ def test_system_harness_and_checkpoint(tmp_path, dev, models):
     other = NeRFSystem(SimpleNamespace(**{**vars(hp), "pretrained": None}), white_back=True)
     load_ckpt(other.nerf_coarse, str(ck), model_name='nerf_coarse')
     assert torch.equal(other.nerf_coarse.rgb[0].bias, torch.from_numpy(params[0]["rgb.0.bias"]))
+
+
+# --------------------------------------------------------------------------- f2: fused loss + Adam
+@pytest.mark.parametrize("tag", ["c64", "c1000", "coarse_only"])
+def test_fused_mse_loss(golden, ops, dev, tag):
+    """nerfmi_mse_loss vs the reference's losses.MSELoss (golden: loss + autograd grads) and the oracle; psnr/mse
+    by-products vs metrics.py's formula."""
+    g = golden("g17_loss_" + tag)
+    fine = g["rgb_fine"] if "rgb_fine" in g else None
+    out4, gc, gf = ops.mse_loss(T(g["rgb_coarse"], dev), T(fine, dev) if fine is not None else None, T(g["targets"], dev))
+    o = O.mse_loss(g["rgb_coarse"], fine, g["targets"])
+    out4 = N(out4)
+    np.testing.assert_allclose(out4[0], g["loss"], rtol=2e-7)
+    np.testing.assert_allclose(out4[0], o["loss"], rtol=2e-7)
+    assert np.array_equal(N(gc), g["g_coarse"])                       # bit-exact: fp32 op by op
+    if fine is not None:
+        assert np.array_equal(N(gf), g["g_fine"])
+        mse_f = np.mean((fine.astype(np.float64) - g["targets"]) ** 2)
+        np.testing.assert_allclose(out4[2], mse_f, rtol=3e-7)
+        np.testing.assert_allclose(out4[3], -10 * np.log10(mse_f), rtol=1e-6)
+    np.testing.assert_allclose(out4[1], np.mean((g["rgb_coarse"].astype(np.float64) - g["targets"]) ** 2), rtol=3e-7)
+
+
+def test_fused_mse_loss_module_autograd(dev):
+    """FusedMSELoss inside autograd: same loss and input gradients as nn.MSELoss, also with a non-unit upstream grad."""
+    from nerf_siren_amd.training import FusedMSELoss
+    c0, f0, t = (T(synth.hash_uniform((257, 3), s), dev) for s in (1, 2, 3))
+    for unit, scale in ((True, 1.0), (False, 0.37)):
+        c, f = c0.clone().requires_grad_(True), f0.clone().requires_grad_(True)
+        (FusedMSELoss(unit_grad=unit)({"rgb_coarse": c, "rgb_fine": f}, t) * scale).backward()
+        c2, f2 = c0.clone().requires_grad_(True), f0.clone().requires_grad_(True)
+        ((torch.nn.functional.mse_loss(c2, t) + torch.nn.functional.mse_loss(f2, t)) * scale).backward()
+        np.testing.assert_allclose(N(c.grad), N(c2.grad), rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(N(f.grad), N(f2.grad), rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag,wd", [("wd0", 0.0), ("wd1e-4", 1e-4)])
+def test_fused_adam_kernel_vs_torch(golden, ops, dev, tag, wd):
+    """nerfmi_adam_step on a flat buffer vs 12 steps of torch.optim.Adam (golden, CPU) and the oracle."""
+    g = golden("g17_adam_" + tag)
+    shapes = [g[f"p0_{i}"].shape for i in range(3)]
+    sizes = [int(np.prod(s)) for s in shapes]
+    flat = T(np.concatenate([g[f"p0_{i}"].reshape(-1) for i in range(3)]), dev)
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    po = [g[f"p0_{i}"].copy() for i in range(3)]
+    mo = [np.zeros_like(p) for p in po]
+    vo = [np.zeros_like(p) for p in po]
+    lr = 5e-4
+    for step in range(12):
+        grads = [synth.hash_normal(shapes[i], 1000 + 10 * step + i) * np.float32(0.1 if step % 3 else 3.0) for i in range(3)]
+        ops.adam_step(flat, T(np.concatenate([x.reshape(-1) for x in grads]), dev), m, v, step + 1, lr, weight_decay=wd)
+        for i in range(3):
+            po[i], mo[i], vo[i] = O.adam_step(po[i], grads[i], mo[i], vo[i], step + 1, lr, weight_decay=wd)
+        if step + 1 in (4, 8):
+            lr *= 0.5
+    got = N(flat)
+    off = 0
+    for i in range(3):
+        np.testing.assert_allclose(got[off:off + sizes[i]].reshape(shapes[i]), g[f"p12_{i}"], rtol=2e-6, atol=1e-8)
+        np.testing.assert_allclose(got[off:off + sizes[i]].reshape(shapes[i]), po[i], rtol=2e-6, atol=1e-8)
+        off += sizes[i]
+
+
+def test_fused_adam_optimizer_matches_torch_on_nerf(dev, models):
+    """FusedAdam (flat parameter/gradient buffers, lr scheduler, packed-weight refresh) vs torch.optim.Adam through
+    five real render_rays training steps: parameters agree to fp32 rounding."""
+    from nerf_siren_amd import Embedding, NeRF, render_rays
+    from nerf_siren_amd.training import FusedAdam, FusedMSELoss
+    params, _ = models
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    rays = T(synth.blender_rays(64, 5), dev)
+    tgt = T(synth.hash_uniform((64, 3), 6), dev)
+
+    def run(fused):
+        ms = []
+        for p in params:
+            m = NeRF()
+            m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+            ms.append(m.to(dev))
+        if fused:
+            opt, loss_fn = FusedAdam(ms, lr=1e-3, eps=1e-8), FusedMSELoss(unit_grad=True)
+        else:
+            opt = torch.optim.Adam([q for m in ms for q in m.parameters()], lr=1e-3, eps=1e-8)
+
+            def loss_fn(r, t):
+                return ((r["rgb_coarse"] - t) ** 2).mean() + ((r["rgb_fine"] - t) ** 2).mean()
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2, 4], gamma=0.5)
+        losses = []
+        for step in range(5):
+            rg = {k: T(v, dev) for k, v in synth.psnr_step_rng(step, 64, 64, 64).items()}
+            res = render_rays(ms, emb, rays, 64, False, 1.0, 0.0, 64, 1 << 15, True, False, rng=rg)
+            loss = loss_fn(res, tgt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            sched.step()
+            losses.append(float(loss))
+        return ms, losses
+
+    ms_f, lf = run(True)
+    ms_t, lt = run(False)
+    np.testing.assert_allclose(lf, lt, rtol=1e-4)
+    assert lf[-1] < lf[0]
+    for a, b in zip(ms_f, ms_t):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa) == list(sb)
+        for k in sa:
+            d = np.abs(N(sa[k]) - N(sb[k]))                 # 5 steps x lr 1e-3 = 5e-3 of motion per element
+            assert (d < 2e-5).mean() > 0.999 and d.max() < 5e-4, (k, d.max())   # near-zero gradients flip Adam's sign

@@ -218,3 +218,34 @@ def test_siren_oracle_vs_reference(golden):
     assert np.abs(film - g["film_out"]).max() < 5e-7
     sig = O.siren_forward(p, g["inp"], g["freq"], g["phase"], g["dirs"], sigma_only=True)
     assert np.array_equal(sig[..., 0], out[..., 3])
+
+
+# --------------------------------------------------------------------------- f2: loss + Adam
+@pytest.mark.parametrize("tag", ["c64", "c1000", "coarse_only"])
+def test_mse_loss_oracle_vs_reference(golden, tag):
+    """losses.MSELoss (imported reference class) + its autograd vs the restatement."""
+    g = golden("g17_loss_" + tag)
+    fine = g["rgb_fine"] if "rgb_fine" in g else None
+    o = O.mse_loss(g["rgb_coarse"], fine, g["targets"])
+    np.testing.assert_allclose(o["loss"], g["loss"], rtol=2e-7)
+    assert np.array_equal(o["g_coarse"], g["g_coarse"])
+    if fine is not None:
+        assert np.array_equal(o["g_fine"], g["g_fine"])
+
+
+@pytest.mark.parametrize("tag,wd", [("wd0", 0.0), ("wd1e-4", 1e-4)])
+def test_adam_oracle_vs_torch(golden, tag, wd):
+    """12 torch.optim.Adam steps (lr 5e-4 halved at steps 4 and 8, eps 1e-8) vs the restatement."""
+    g = golden("g17_adam_" + tag)
+    ps = [g[f"p0_{i}"].copy() for i in range(3)]
+    ms = [np.zeros_like(p) for p in ps]
+    vs = [np.zeros_like(p) for p in ps]
+    lr = 5e-4
+    for step in range(12):
+        for i in range(3):
+            grad = synth.hash_normal(ps[i].shape, 1000 + 10 * step + i) * np.float32(0.1 if step % 3 else 3.0)
+            ps[i], ms[i], vs[i] = O.adam_step(ps[i], grad, ms[i], vs[i], step + 1, lr, weight_decay=wd)
+        if step + 1 in (4, 8):
+            lr *= 0.5
+    for i in range(3):
+        np.testing.assert_allclose(ps[i], g[f"p12_{i}"], rtol=2e-6, atol=1e-8)

@@ -44,10 +44,10 @@ def _worker(rank, world, port, q):
     flat1 = torch.cat([p.grad.reshape(-1) for p in models[1].parameters()])
     off = 0
     for p in models[1].parameters():
-        p.grad = flat1[off:off + p.numel()].view_as(p)
+        p.grad = flat1[off:off + p.numel()].view_as(p).detach()     # autograd hands gradients over detached (no ._base)
         off += p.numel()
     bases = red.all_reduce()
-    assert len(bases) == 1 and bases[0] is flat1
+    assert len(bases) == 1 and bases[0].data_ptr() == flat1.data_ptr() and bases[0].numel() == flat1.numel()
     flat = torch.cat([p.grad.reshape(-1) for m in models for p in m.parameters()])
     q.put((rank, flat))
     dist.barrier()

@@ -448,7 +448,41 @@ def g_eg3d_grad():
         save("g16_eg3d_grad_" + tag, **out)
 
 
+def g_loss():
+    """losses.py:10-20 MSELoss (the reference class, imported) + autograd; the Adam reference is torch.optim.Adam
+    itself (utils/__init__.py:20 -- utils/ cannot be imported here: torchvision is absent), stepped on CPU."""
+    import losses as L                                 # reference
+    for tag, n, fine in (("c64", 64, True), ("c1000", 1000, True), ("coarse_only", 37, False)):
+        c = torch.from_numpy(synth.hash_uniform((n, 3), 900)).requires_grad_(True)
+        f = torch.from_numpy(synth.hash_uniform((n, 3), 901)).requires_grad_(True)
+        t = torch.from_numpy(synth.hash_uniform((n, 3), 902))
+        inputs = {"rgb_coarse": c}
+        if fine:
+            inputs["rgb_fine"] = f
+        loss = L.MSELoss()(inputs, t)
+        loss.backward()
+        out = dict(rgb_coarse=c.detach(), targets=t, loss=loss.detach(), g_coarse=c.grad)
+        if fine:
+            out.update(rgb_fine=f.detach(), g_fine=f.grad)
+        save("g17_loss_" + tag, **out)
+    # Adam trajectory: 12 steps on a 3-tensor parameter set with hash gradients, MultiStepLR-like lr drop, wd 0 / 1e-4
+    for tag, wd in (("wd0", 0.0), ("wd1e-4", 1e-4)):
+        ps = [torch.from_numpy(synth.hash_normal(sh, 910 + i)).requires_grad_(True) for i, sh in enumerate([(7, 5), (5,), (3, 11)])]
+        opt = torch.optim.Adam(ps, lr=5e-4, eps=1e-8, weight_decay=wd)
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[4, 8], gamma=0.5)
+        out = {f"p0_{i}": p.detach().clone() for i, p in enumerate(ps)}
+        for step in range(12):
+            for i, p in enumerate(ps):
+                p.grad = torch.from_numpy(synth.hash_normal(tuple(p.shape), 1000 + 10 * step + i) * (0.1 if step % 3 else 3.0))
+            opt.step()
+            sched.step()
+        out.update({f"p12_{i}": p.detach().clone() for i, p in enumerate(ps)})
+        save("g17_adam_" + tag, **out)
+
+
 def main():
+    if "--only-loss" in sys.argv:
+        return g_loss()
     if "--only-eg3d-grad" in sys.argv:
         return g_eg3d_grad()
     if "--only-siren" in sys.argv:
@@ -458,6 +492,7 @@ def main():
     g_eg3d()
     g_eg3d_grad()
     g_siren()
+    g_loss()
     g_primitives()
     g_composite()
     g_sample_pdf()
