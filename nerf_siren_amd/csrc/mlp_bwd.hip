@@ -307,8 +307,18 @@ __global__ void nerf_dw_reduce_kernel(DwPlan plan, const float *__restrict__ par
     const int out_f_valid = T.a_valid, in_valid = T.b_valid;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < slab; idx += gridDim.x * blockDim.x) {
         const float *src = partial + T.part_off + idx;
+        // fixed summation order (bit-reproducible); unrolled so the slab loads of a thread are all in flight at once
+        // instead of one HBM round trip per chunk
         float s = 0.f;
-        for (int c = 0; c < T.chunks; ++c) s += src[(int64_t)c * slab];
+        int c = 0;
+        for (; c + 8 <= T.chunks; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(c + u) * slab];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c < T.chunks; ++c) s += src[(int64_t)c * slab];
         if (idx < rows * cols) {
             const int j = idx / cols, k = idx % cols;
             if (j < out_f_valid && k < in_valid) G.p[T.param][j * T.in_f + T.out_col0 + k] = s;
@@ -413,7 +423,7 @@ int nerfmi_nerf_backward_rays(const float *packed, const float *rays, const floa
         lds_attr_set = true;
     }
     hipLaunchKernelGGL(nerf_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
-    hipLaunchKernelGGL(nerf_dw_reduce_kernel, dim3(64, P.n_tasks), dim3(256), 0, st, P, partial, G);
+    hipLaunchKernelGGL(nerf_dw_reduce_kernel, dim3(128, P.n_tasks), dim3(256), 0, st, P, partial, G);
     return check_launch("nerf_backward_rays");
 }
 
