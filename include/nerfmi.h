@@ -162,6 +162,27 @@ int nerfmi_importance_resample(const float *z_coarse, const float *weights_coars
                                int n_samples, int n_importance, float *z_new_out, float *z_fine_out,
                                nerfmi_stream_t stream);
 
+/* ==== the step before the path: ray generation on the device ========================
+ * datasets/ray_utils.py:5-24 get_ray_directions(H, W, focal) -> dirs_out (H, W, 3): ((i-W/2)/focal, -(j-H/2)/focal, -1),
+ * i = column, j = row (kornia.create_meshgrid(H, W, normalized_coordinates=False)). */
+int nerfmi_ray_directions(int H, int W, double focal, float *dirs_out, nerfmi_stream_t stream);
+
+/* datasets/ray_utils.py:27-50 get_rays(directions (n,3), c2w (3,4) row-major) -> rays_o (n,3) = c2w[:,3],
+ * rays_d (n,3) = normalised directions @ c2w[:, :3].T */
+int nerfmi_get_rays(const float *directions, const float *c2w, int64_t n, float *rays_o_out, float *rays_d_out,
+                    nerfmi_stream_t stream);
+
+/* datasets/ray_utils.py:53-93 get_ndc_rays(H, W, focal, near, rays_o, rays_d) */
+int nerfmi_ndc_rays(int H, int W, double focal, double near, const float *rays_o, const float *rays_d, int64_t n,
+                    float *rays_o_out, float *rays_d_out, nerfmi_stream_t stream);
+
+/* The three above fused with the (N,8) [o, d, near, far] packing of datasets/blender.py:60-69 (ndc = 0, near/far as
+ * given: 2 / 6) and datasets/llff.py:234-250 (ndc != 0: get_ndc_rays with near plane 1.0, bounds 0 / 1).
+ * c2w (n_images,3,4); pixel_index (n_rays) int64 = image*H*W + row*W + column, or NULL for every pixel of every
+ * image in order (then n_rays = n_images*H*W).  rays_out (n_rays, 8). */
+int nerfmi_generate_rays(const float *c2w, int n_images, int H, int W, double focal, const int64_t *pixel_index,
+                         int64_t n_rays, int ndc, double near, double far, float *rays_out, nerfmi_stream_t stream);
+
 /* ==== the step after the path in training ===========================================
  * losses.py:10-20 MSELoss = nn.MSELoss(mean)(rgb_coarse, t) [+ nn.MSELoss(mean)(rgb_fine, t)], its autograd
  * (d x = (2/n_elems) * (x - t) * grad_out) and metrics.py:4-13 psnr = -10 log10(mse), in one launch.

@@ -21,6 +21,12 @@ def __getattr__(name):
     if name in ("ImportanceRenderer", "MipRayMarcher2", "RaySampler"):
         from . import volumetric_rendering
         return getattr(volumetric_rendering, name)
+    if name in ("FusedAdam", "FusedMSELoss"):
+        from . import training
+        return getattr(training, name)
+    if name in ("get_ray_directions", "get_rays", "get_ndc_rays", "generate_rays"):
+        from . import ray_utils
+        return getattr(ray_utils, name)
     if name == "searchsorted":
         from . import ops
         return ops.searchsorted

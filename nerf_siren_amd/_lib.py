@@ -60,6 +60,10 @@ SIGNATURES = {
     "nerfmi_search_lerp": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _f]),
     "nerfmi_searchsorted": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "nerfmi_merge_sorted": (_i, [_f, _f, _i, _i, _i, _f, _f]),
+    "nerfmi_ray_directions": (_i, [_i, _i, C.c_double, _f, _f]),
+    "nerfmi_get_rays": (_i, [_f, _f, _i64, _f, _f, _f]),
+    "nerfmi_ndc_rays": (_i, [_i, _i, C.c_double, C.c_double, _f, _f, _i64, _f, _f, _f]),
+    "nerfmi_generate_rays": (_i, [_f, _i, _i, _i, C.c_double, _f, _i64, _i, C.c_double, C.c_double, _f, _f]),
     "nerfmi_mse_loss": (_i, [_f, _f, _f, _i64, _fl, _f, _f, _f, _f]),
     "nerfmi_adam_step": (_i, [_f, _f, _f, _f, _i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64,
                              C.c_double, _f]),

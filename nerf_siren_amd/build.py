@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libnerfmi.so")
-SOURCES = ["rays.hip", "mlp.hip", "mlp_bwd.hip", "siren.hip", "eg3d.hip", "eg3d_bwd.hip", "mlp_bf16x3.hip", "train_step.hip"]
+SOURCES = ["rays.hip", "mlp.hip", "mlp_bwd.hip", "siren.hip", "eg3d.hip", "eg3d_bwd.hip", "mlp_bf16x3.hip", "train_step.hip", "raygen.hip"]
 HEADERS = ["common.h", "mlp_layout.h", "mlp_core.h", os.path.join("..", "..", "include", "nerfmi.h")]
 # -ffp-contract=off: the per-ray kernels reproduce torch's op-by-op fp32 rounding
 # (oracle/nerf_oracle.py); fused multiply-adds are written explicitly where wanted.

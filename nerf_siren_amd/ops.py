@@ -358,3 +358,51 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), ep
     check(_lib.lib().nerfmi_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), n, float(lr),
                                       float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
                                       float(grad_scale), _stream(param)), "adam_step")
+
+
+# --------------------------------------------------------------------------- f1: ray generation
+def ray_directions(H, W, focal, device):
+    """datasets/ray_utils.py:5-24 get_ray_directions -> (H, W, 3) on `device`."""
+    out = torch.empty((int(H), int(W), 3), device=device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_ray_directions(int(H), int(W), float(focal), ptr(out), _stream(out)), "ray_directions")
+    return out
+
+
+def get_rays(directions, c2w):
+    """datasets/ray_utils.py:27-50 get_rays(directions (...,3), c2w (3,4)) -> rays_o (n,3), rays_d (n,3)."""
+    directions = _req(directions, "directions")
+    c2w = _req(c2w, "c2w", (3, 4))
+    if directions.shape[-1] != 3:
+        raise ValueError("directions must end in a dimension of 3")
+    n = directions.numel() // 3
+    o = torch.empty((n, 3), device=directions.device, dtype=torch.float32)
+    d = torch.empty_like(o)
+    check(_lib.lib().nerfmi_get_rays(ptr(directions), ptr(c2w), n, ptr(o), ptr(d), _stream(o)), "get_rays")
+    return o, d
+
+
+def get_ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """datasets/ray_utils.py:53-93 (near: float)."""
+    rays_o = _req(rays_o, "rays_o", (None, 3))
+    rays_d = _req(rays_d, "rays_d", (rays_o.shape[0], 3))
+    o, d = torch.empty_like(rays_o), torch.empty_like(rays_d)
+    check(_lib.lib().nerfmi_ndc_rays(int(H), int(W), float(focal), float(near), ptr(rays_o), ptr(rays_d), rays_o.shape[0],
+                                     ptr(o), ptr(d), _stream(o)), "ndc_rays")
+    return o, d
+
+
+def generate_rays(c2w, H, W, focal, pixel_index=None, ndc=False, near=2.0, far=6.0):
+    """(n_rays, 8) [o, d, near, far] straight from (c2w (n_images,3,4), focal, pixel index): the fused form of
+    get_ray_directions + get_rays (+ get_ndc_rays) + the packing of blender.py:60-69 / llff.py:234-250."""
+    c2w = _req(c2w.reshape(-1, 3, 4), "c2w")
+    n_img = c2w.shape[0]
+    if pixel_index is None:
+        n = n_img * int(H) * int(W)
+    else:
+        pixel_index = _req(pixel_index, "pixel_index", (None,), dtype=torch.int64)
+        n = pixel_index.shape[0]
+    rays = torch.empty((n, 8), device=c2w.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_generate_rays(ptr(c2w), n_img, int(H), int(W), float(focal), ptr(pixel_index), n,
+                                          int(bool(ndc)), float(near), float(far), ptr(rays), _stream(rays)),
+          "generate_rays")
+    return rays

@@ -473,3 +473,69 @@ def adam_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0
     denom = ((np.sqrt(v).astype(F32) / F32(bc2_sqrt)).astype(F32) + F32(eps)).astype(F32)
     p = (p + ((F32(-step_size) * m).astype(F32) / denom).astype(F32)).astype(F32)
     return p, m, v
+
+
+# ----------------------------------------------------------------------------
+# f1  the step before the path: datasets/ray_utils.py:5-93 and the (N,8) packing of
+#     datasets/blender.py:60-69 / datasets/llff.py:234-250.
+#     PARITY UNPINNED for this block: ray_utils.py imports kornia at module level and kornia is absent, so the
+#     reference's functions cannot be executed here; they are restated line by line (create_meshgrid(H, W, False)
+#     = integer pixel coordinates, i = column, j = row) and tests check the restatement against the same
+#     formulas evaluated with torch CPU ops.
+# ----------------------------------------------------------------------------
+def ray_directions(H: int, W: int, focal: float) -> np.ndarray:
+    """get_ray_directions: (H, W, 3) = ((i - W/2)/focal, -(j - H/2)/focal, -1)."""
+    i = np.broadcast_to(np.arange(W, dtype=F32)[None, :], (H, W))
+    j = np.broadcast_to(np.arange(H, dtype=F32)[:, None], (H, W))
+    f = F32(focal)
+    dx = ((i - F32(W / 2)).astype(F32) / f).astype(F32)
+    dy = ((-(j - F32(H / 2)).astype(F32)) / f).astype(F32)
+    return np.stack([dx, dy, -np.ones_like(dx)], -1).astype(F32)
+
+
+def get_rays(directions, c2w):
+    """get_rays: directions (...,3), c2w (3,4) -> rays_o (n,3), rays_d (n,3) (normalised)."""
+    d = np.asarray(directions, F32).reshape(-1, 3)
+    c = np.asarray(c2w, F32)
+    r = np.stack([(((d[:, 0] * c[k, 0]).astype(F32) + (d[:, 1] * c[k, 1]).astype(F32)).astype(F32)
+                   + (d[:, 2] * c[k, 2]).astype(F32)).astype(F32) for k in range(3)], -1)
+    r = (r / ray_norm(r)[:, None]).astype(F32)
+    return np.broadcast_to(c[:, 3], r.shape).astype(F32), r
+
+
+def ndc_rays(H: int, W: int, focal: float, near: float, rays_o, rays_d):
+    """get_ndc_rays, fp32 op by op; Python-float constants formed in double and rounded once."""
+    o = np.asarray(rays_o, F32)
+    d = np.asarray(rays_d, F32)
+    t = ((-(F32(near) + o[:, 2]).astype(F32)) / d[:, 2]).astype(F32)
+    o = (o + (t[:, None] * d).astype(F32)).astype(F32)
+    ox_oz = (o[:, 0] / o[:, 2]).astype(F32)
+    oy_oz = (o[:, 1] / o[:, 2]).astype(F32)
+    cw, ch = F32(-1.0 / (W / (2.0 * focal))), F32(-1.0 / (H / (2.0 * focal)))
+    o0 = (cw * ox_oz).astype(F32)
+    o1 = (ch * oy_oz).astype(F32)
+    o2 = (F32(1) + ((F32(1) / o[:, 2]).astype(F32) * F32(2.0 * near)).astype(F32)).astype(F32)   # scalar / tensor = reciprocal * scalar
+    d0 = (cw * ((d[:, 0] / d[:, 2]).astype(F32) - ox_oz).astype(F32)).astype(F32)
+    d1 = (ch * ((d[:, 1] / d[:, 2]).astype(F32) - oy_oz).astype(F32)).astype(F32)
+    d2 = (F32(1) - o2).astype(F32)
+    return np.stack([o0, o1, o2], -1).astype(F32), np.stack([d0, d1, d2], -1).astype(F32)
+
+
+def generate_rays(c2w, H: int, W: int, focal: float, pixel_index=None, ndc: bool = False, near: float = 2.0,
+                  far: float = 6.0) -> np.ndarray:
+    """(n,8) [o, d, near, far] rows for pixel_index = image*H*W + row*W + column (default: all pixels of all images)."""
+    c2w = np.asarray(c2w, F32).reshape(-1, 3, 4)
+    if pixel_index is None:
+        pixel_index = np.arange(c2w.shape[0] * H * W, dtype=np.int64)
+    pixel_index = np.asarray(pixel_index, np.int64)
+    dirs = ray_directions(H, W, focal).reshape(-1, 3)
+    img, pix = pixel_index // (H * W), pixel_index % (H * W)
+    out = np.empty((pixel_index.size, 8), F32)
+    for k in np.unique(img):
+        sel = img == k
+        o, d = get_rays(dirs[pix[sel]], c2w[k])
+        if ndc:
+            o, d = ndc_rays(H, W, focal, 1.0, o, d)
+        out[sel, 0:3], out[sel, 3:6] = o, d
+    out[:, 6], out[:, 7] = (0.0, 1.0) if ndc else (near, far)
+    return out

@@ -842,3 +842,51 @@ def test_fused_adam_optimizer_matches_torch_on_nerf(dev, models):
         for k in sa:
             d = np.abs(N(sa[k]) - N(sb[k]))                 # 5 steps x lr 1e-3 = 5e-3 of motion per element
             assert (d < 2e-5).mean() > 0.999 and d.max() < 5e-4, (k, d.max())   # near-zero gradients flip Adam's sign
+
+
+# --------------------------------------------------------------------------- f1: ray generation on the device
+@pytest.mark.parametrize("H,W,focal,n_img,ndc", [(5, 7, 6.3, 1, False), (40, 40, 55.5555, 3, False),
+                                                 (27, 36, 0.809 * 36, 2, True), (1, 1, 1.0, 1, False),
+                                                 (400, 400, 555.5555, 2, False)])
+def test_generate_rays_vs_oracle(ops, dev, H, W, focal, n_img, ndc):
+    """nerfmi_generate_rays / ray_directions / get_rays / ndc_rays vs the restatement of datasets/ray_utils.py:
+    bit-exact (same fp32 operation order), all pixels and a ragged pixel-index pick."""
+    from nerf_siren_amd import ray_utils as RU
+    if ndc:
+        c2w = np.stack([np.concatenate([np.eye(3, dtype=np.float32), np.float32([[0.1 * k], [-0.05], [0.2]])], 1)
+                        for k in range(n_img)])
+    else:
+        c2w = np.stack([synth._look_at_c2w(0.3 + 0.2 * k, 1.1 * k, 4.0311) for k in range(n_img)]).astype(np.float32)
+    ref = O.generate_rays(c2w, H, W, focal, ndc=ndc)
+    got = N(RU.generate_rays(T(c2w, dev), H, W, focal, ndc=ndc))
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    idx = (synth.hash_uniform((37,), 5) * (n_img * H * W)).astype(np.int64).clip(0, n_img * H * W - 1)
+    got_i = N(RU.generate_rays(T(c2w, dev), H, W, focal, pixel_index=torch.from_numpy(idx).to(dev), ndc=ndc))
+    assert np.array_equal(got_i, ref[idx])
+    # the three reference-named pieces
+    dirs = RU.get_ray_directions(H, W, focal, dev)
+    assert np.array_equal(N(dirs), O.ray_directions(H, W, focal))
+    o, d = RU.get_rays(dirs, T(c2w[0], dev))
+    o_ref, d_ref = O.get_rays(O.ray_directions(H, W, focal), c2w[0])
+    assert np.array_equal(N(o), o_ref) and np.array_equal(N(d), d_ref)
+    if ndc:
+        o2, d2 = RU.get_ndc_rays(H, W, focal, 1.0, o, d)
+        o2_ref, d2_ref = O.ndc_rays(H, W, focal, 1.0, o_ref, d_ref)
+        assert np.array_equal(N(o2), o2_ref) and np.array_equal(N(d2), d2_ref)
+        assert np.array_equal(got[:H * W, :3], o2_ref) and np.array_equal(got[:H * W, 3:6], d2_ref)
+
+
+def test_generate_rays_feeds_render_rays(dev, models):
+    """Rays produced on the device render exactly like the same rays uploaded from the host."""
+    from nerf_siren_amd import Embedding, render_rays, ray_utils as RU
+    _, ms = models
+    c2w = np.stack([synth._look_at_c2w(0.5, 0.7, 4.0311)]).astype(np.float32)
+    idx = np.arange(0, 64 * 64, 41, dtype=np.int64)
+    rays_dev = RU.generate_rays(T(c2w, dev), 64, 64, 88.9, pixel_index=torch.from_numpy(idx).to(dev))
+    rays_host = T(O.generate_rays(c2w, 64, 64, 88.9, pixel_index=idx), dev)
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    with torch.no_grad():
+        a = render_rays(ms, emb, rays_dev, 64, False, 0, 0, 64, 1 << 15, True, True)
+        b = render_rays(ms, emb, rays_host, 64, False, 0, 0, 64, 1 << 15, True, True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

@@ -249,3 +249,61 @@ def test_adam_oracle_vs_torch(golden, tag, wd):
             lr *= 0.5
     for i in range(3):
         np.testing.assert_allclose(ps[i], g[f"p12_{i}"], rtol=2e-6, atol=1e-8)
+
+
+# --------------------------------------------------------------------------- f1: ray generation (parity unpinned)
+def _torch_ray_formulas(c2w, H, W, focal, ndc):
+    """datasets/ray_utils.py:5-93 re-typed with torch CPU ops (the reference module itself needs kornia, absent here):
+    this is what the reference executes, given create_meshgrid(H, W, False) = integer pixel coordinates."""
+    import torch
+    j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    directions = torch.stack([(i - W / 2) / focal, -(j - H / 2) / focal, -torch.ones_like(i)], -1)
+    c2w = torch.from_numpy(c2w)
+    rays_d = directions @ c2w[:, :3].T
+    rays_d = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    rays_o = c2w[:, 3].expand(rays_d.shape)
+    rays_d, rays_o = rays_d.reshape(-1, 3), rays_o.reshape(-1, 3)
+    if ndc:
+        near = 1.0
+        t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+        rays_o = rays_o + t[..., None] * rays_d
+        ox_oz = rays_o[..., 0] / rays_o[..., 2]
+        oy_oz = rays_o[..., 1] / rays_o[..., 2]
+        o0 = -1. / (W / (2. * focal)) * ox_oz
+        o1 = -1. / (H / (2. * focal)) * oy_oz
+        o2 = 1. + 2. * near / rays_o[..., 2]
+        d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - ox_oz)
+        d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - oy_oz)
+        d2 = 1 - o2
+        rays_o, rays_d = torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+    return directions.numpy(), rays_o.numpy(), rays_d.numpy()
+
+
+@pytest.mark.parametrize("H,W,focal,ndc", [(5, 7, 6.3, False), (40, 40, 55.5555, False), (27, 36, 0.809 * 36, True),
+                                           (1, 1, 1.0, False)])
+def test_raygen_oracle_vs_torch_formulas(H, W, focal, ndc):
+    c2w = synth._look_at_c2w(0.4, 1.1, 4.0311).astype(np.float32) if not ndc else \
+        np.concatenate([np.eye(3, dtype=np.float32), np.array([[0.1], [-0.05], [0.2]], np.float32)], 1)
+    dirs, o_t, d_t = _torch_ray_formulas(c2w, H, W, focal, ndc)
+    assert np.array_equal(O.ray_directions(H, W, focal), dirs)                       # exact: integer grid, one sub + one div
+    rays = O.generate_rays(c2w[None], H, W, focal, ndc=ndc)
+    # the (H*W,3)@(3,3) product's summation order / fma use inside torch's matmul is unspecified: a few ulp
+    np.testing.assert_allclose(rays[:, 3:6], d_t, rtol=4e-6, atol=1e-7)
+    np.testing.assert_allclose(rays[:, 0:3], o_t, rtol=4e-6, atol=1e-7)
+    assert np.array_equal(rays[:, 6:], np.broadcast_to(np.float32([0, 1] if ndc else [2, 6]), (H * W, 2)))
+
+
+def test_raygen_oracle_matches_synthetic_ray_pool():
+    """The bench / golden inputs (synth.blender_rays) are the same arithmetic: picking those pixels through the oracle
+    reproduces them."""
+    W = H = 400
+    focal = np.float32(0.5 * W / np.tan(0.5 * synth.LEGO_ANGLE_X))
+    uv = synth.hash_uniform((100, 2), 3 * 7919 + 11)
+    c2ws = np.stack([synth._look_at_c2w(e, a, synth.LEGO_RADIUS) for e, a in
+                     zip(uv[:, 0].astype(np.float64) * np.deg2rad(60.0), uv[:, 1].astype(np.float64) * 2 * np.pi)])
+    pick = synth.hash_uniform((64, 3), 3 * 7919 + 13)
+    v = np.minimum((pick[:, 0] * 100).astype(np.int64), 99)
+    i = np.minimum((pick[:, 1] * W).astype(np.int64), W - 1)
+    j = np.minimum((pick[:, 2] * H).astype(np.int64), H - 1)
+    rays = O.generate_rays(c2ws.astype(np.float32), H, W, float(focal), pixel_index=v * H * W + j * W + i)
+    np.testing.assert_allclose(rays, synth.blender_rays(64, 3), rtol=2e-6, atol=1e-7)
