@@ -1,0 +1,73 @@
+"""Dense field queries: the same MLP kernel without ray structure.
+
+    query_field   NeRF()(cat[Embedding(xyz), Embedding(dir)]) for arbitrary points -- the chunk loop of
+                  extract_color_mesh.py:128-137 / extract_mesh.ipynb cell 4 as ONE launch per chunk: a point is a
+                  "ray" with origin xyz, direction dir and a single sample at depth 0 (xyz + dir*0 == xyz exactly),
+                  so the fused embed+MLP kernel runs unchanged and reads 36 B per point instead of a 360 B
+                  pre-embedded row
+    sigma_grid    the N^3 occupancy grid of extract_color_mesh.py:117-140 (np.meshgrid 'xy' ordering, zero
+                  directions, sigma clamped at 0)
+    pack_vol      the sparse `.vol` records of extract_mesh.ipynb cell 7 (uint32 pairs [voxel index, r<<24|g<<16|b<<8|a])
+
+marching cubes / mesh colouring (PyMCubes, open3d) stay on the host and out of scope.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def query_field(model, xyz, dirs=None, sigma_only=False, chunk=1 << 22):
+    """xyz (B,3) fp32 on the GPU, dirs (B,3) or None (= zeros, 'sigma is independent of direction',
+    extract_color_mesh.py:124) -> (B,4) [rgb, sigma] or (B,1) sigma."""
+    xyz = xyz.reshape(-1, 3).float().contiguous()
+    B = xyz.shape[0]
+    packed = model.packed()
+    outs = []
+    for i in range(0, B, chunk):
+        x = xyz[i:i + chunk]
+        n = x.shape[0]
+        rays = torch.zeros((n, 8), device=x.device, dtype=torch.float32)
+        rays[:, 0:3] = x
+        if dirs is not None:
+            rays[:, 3:6] = dirs.reshape(-1, 3)[i:i + chunk]
+        z = torch.zeros((n, 1), device=x.device, dtype=torch.float32)
+        out = ops.nerf_forward_rays(packed, rays, z, sigma_only=sigma_only)
+        outs.append(out.reshape(n, -1))
+    return torch.cat(outs, 0) if len(outs) != 1 else outs[0]
+
+
+def grid_points(N, x_range, y_range, z_range, device):
+    """xyz_ of extract_color_mesh.py:117-122: np.linspace in fp64, np.meshgrid (default 'xy' indexing), stacked and
+    rounded to fp32 -> (N^3, 3); flat index = (iy*N + ix)*N + iz."""
+    x = torch.linspace(x_range[0], x_range[1], N, dtype=torch.float64, device=device)
+    y = torch.linspace(y_range[0], y_range[1], N, dtype=torch.float64, device=device)
+    z = torch.linspace(z_range[0], z_range[1], N, dtype=torch.float64, device=device)
+    gy, gx, gz = torch.meshgrid(y, x, z, indexing="ij")          # == np.meshgrid(x, y, z) ('xy')
+    return torch.stack([gx, gy, gz], -1).reshape(-1, 3).float()
+
+
+def sigma_grid(model, N, x_range, y_range, z_range, chunk=1 << 22, return_rgbsigma=False):
+    """(N,N,N) occupancy grid max(sigma, 0) (extract_color_mesh.py:139-140), on the GPU."""
+    dev = next(model.parameters()).device
+    pts = grid_points(N, x_range, y_range, z_range, dev)
+    with torch.no_grad():
+        rgbsigma = query_field(model, pts, None, sigma_only=not return_rgbsigma, chunk=chunk)
+    sigma = torch.clamp_min(rgbsigma[:, -1], 0).reshape(N, N, N)
+    return (sigma, rgbsigma) if return_rgbsigma else sigma
+
+
+def pack_vol(rgbsigma, N, extent) -> np.ndarray:
+    """extract_mesh.ipynb cell 7: a = 1 - exp(-extent/N * relu(sigma)); keep a > 0; records uint32
+    [index, (r<<24)|(g<<16)|(b<<8)|a] with r,g,b = trunc(rgb*255), a = trunc(a*255).  Returns the flat uint32
+    array whose bytes are the `.vol` file (extent = xmax - xmin)."""
+    rgbsigma = rgbsigma.reshape(-1, 4).float()
+    sigma = torch.clamp_min(rgbsigma[:, 3], 0)
+    a = 1 - torch.exp(sigma * (-float(extent) / N))                  # fp32, like numpy on a float32 array
+    idx = torch.nonzero(a > 0).reshape(-1)
+    rgb = (rgbsigma[idx, :3] * 255).to(torch.int64)                  # astype(uint32) of non-negative values
+    s = (rgb[:, 0] << 24) + (rgb[:, 1] << 16) + (rgb[:, 2] << 8) + (a[idx] * 255).to(torch.int64)
+    res = torch.stack([idx, s], -1).reshape(-1)
+    return (res & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)

@@ -539,3 +539,34 @@ def generate_rays(c2w, H: int, W: int, focal: float, pixel_index=None, ndc: bool
         out[sel, 0:3], out[sel, 3:6] = o, d
     out[:, 6], out[:, 7] = (0.0, 1.0) if ndc else (near, far)
     return out
+
+
+# ----------------------------------------------------------------------------
+# f3  dense field query: extract_color_mesh.py:117-140, extract_mesh.ipynb cells 4 and 7 (restated; the scripts
+#     themselves need mcubes/open3d/datasets and cannot run here -- the field evaluation they call is pinned above)
+# ----------------------------------------------------------------------------
+def grid_points(N, x_range, y_range, z_range):
+    x = np.linspace(x_range[0], x_range[1], N)
+    y = np.linspace(y_range[0], y_range[1], N)
+    z = np.linspace(z_range[0], z_range[1], N)
+    return np.stack(np.meshgrid(x, y, z), -1).reshape(-1, 3).astype(F32)
+
+
+def query_field(p: dict, xyz, dirs=None, sigma_only=False):
+    xyz = np.asarray(xyz, F32).reshape(-1, 3)
+    dirs = np.zeros_like(xyz) if dirs is None else np.asarray(dirs, F32).reshape(-1, 3)
+    x = np.concatenate([embed(xyz, 10), embed(dirs, 4)], -1)
+    return nerf_forward(p, x[:, :63] if sigma_only else x, sigma_only=sigma_only)
+
+
+def pack_vol(rgbsigma, N, extent):
+    rgbsigma = np.asarray(rgbsigma, F32).reshape(-1, 4)
+    sigma = np.maximum(rgbsigma[:, -1], 0)
+    a = 1 - np.exp(-(extent) / N * sigma)
+    a = a.flatten()
+    rgb = (rgbsigma[:, :3] * 255).astype(np.uint32)
+    i = np.where(a > 0)[0]
+    rgb = rgb[i]
+    a = a[i]
+    s = rgb.dot(np.array([1 << 24, 1 << 16, 1 << 8])) + (a * 255).astype(np.uint32)
+    return np.stack([i, s], -1).astype(np.uint32).flatten()

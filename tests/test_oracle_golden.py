@@ -307,3 +307,20 @@ def test_raygen_oracle_matches_synthetic_ray_pool():
     j = np.minimum((pick[:, 2] * H).astype(np.int64), H - 1)
     rays = O.generate_rays(c2ws.astype(np.float32), H, W, float(focal), pixel_index=v * H * W + j * W + i)
     np.testing.assert_allclose(rays, synth.blender_rays(64, 3), rtol=2e-6, atol=1e-7)
+
+
+# --------------------------------------------------------------------------- f4: PFM files
+def test_pfm_writer_matches_reference_bytes(golden, tmp_path):
+    """io_utils.save_pfm writes byte-identical files to datasets/depth_utils.save_pfm; read_pfm round-trips them."""
+    from nerf_siren_amd.io_utils import read_pfm, save_pfm
+    g = golden("g18_pfm")
+    for tag, scale in (("gray", 1), ("gray1", 1), ("color", 2.5)):
+        f = tmp_path / f"{tag}.pfm"
+        save_pfm(str(f), g["img_" + tag], scale=scale)
+        assert np.array_equal(np.frombuffer(f.read_bytes(), np.uint8), g["bytes_" + tag]), tag
+        if tag != "gray1":
+            back, sc = read_pfm(str(f))
+            assert np.array_equal(back, g["back_" + tag]) and sc == float(g["scale_" + tag])
+            assert np.array_equal(back, g["img_" + tag])
+    with pytest.raises(Exception):
+        save_pfm(str(tmp_path / "bad.pfm"), np.zeros((2, 2), np.float64))

@@ -480,7 +480,31 @@ def g_loss():
         save("g17_adam_" + tag, **out)
 
 
+def g_pfm():
+    """datasets/depth_utils.py save_pfm / read_pfm (imported reference): arrays -> file bytes."""
+    import tempfile
+    import importlib.util
+    # the file itself needs numpy only; its package __init__ pulls torchvision (absent), so load the file directly
+    spec = importlib.util.spec_from_file_location("ref_depth_utils", "/root/reference/datasets/depth_utils.py")
+    du = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(du)
+    read_pfm, save_pfm = du.read_pfm, du.save_pfm
+    out = {}
+    for tag, shape in (("gray", (5, 7)), ("gray1", (4, 3, 1)), ("color", (3, 6, 3))):
+        img = synth.hash_normal(shape, 77).astype(np.float32)
+        with tempfile.NamedTemporaryFile(suffix=".pfm") as f:
+            save_pfm(f.name, img, scale=1 if tag != "color" else 2.5)
+            out["bytes_" + tag] = np.frombuffer(open(f.name, "rb").read(), np.uint8)
+            if tag != "gray1":                                # the reference's reader cannot reshape (H,W,1) files back
+                back, sc = read_pfm(f.name)
+                out["back_" + tag], out["scale_" + tag] = back, np.float64(sc)
+        out["img_" + tag] = img
+    save("g18_pfm", **out)
+
+
 def main():
+    if "--only-pfm" in sys.argv:
+        return g_pfm()
     if "--only-loss" in sys.argv:
         return g_loss()
     if "--only-eg3d-grad" in sys.argv:
@@ -493,6 +517,7 @@ def main():
     g_eg3d_grad()
     g_siren()
     g_loss()
+    g_pfm()
     g_primitives()
     g_composite()
     g_sample_pdf()
