@@ -27,17 +27,6 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&sp)[3]) {
         sp[0][j] = h; sp[1][j] = m; sp[2][j] = (__bf16)r2;
     }
 }
-// registers 8s..8s+7 of a block are k-step s of the next layer (units 16s + 8(t>>2) + 4half + (t&3))
-__device__ __forceinline__ void split_block(const f32x16 &v, bf16x8 (&out)[2][3]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        float x[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] = v[8 * s + t];
-        split8(x, out[s]);
-    }
-}
-
 // fast image: per layer, unit U = (kb*2 + s)*JB + jb (input-block-major: a layer walks its INPUT blocks in the
 // outer loop, so each input block is split just before use and all JB accumulators advance together);
 // unit -> 3 x 1 KiB: split i at bytes (unit_base + U)*3072 + i*1024 + lane*16 (8 bf16).  Built from the fp32
@@ -74,43 +63,79 @@ __global__ void pack_bf16x3_kernel(const float *__restrict__ packed, __bf16 *__r
 #define NERFMI_US 8
 #endif
 constexpr int US = NERFMI_US;                          // units per stage
-constexpr int FSLOT = 3;
-constexpr int FLDS_BYTES = FSLOT * US * 3072;
+constexpr int FSLOT = 4;
+constexpr int FLDS_BYTES = FSLOT * US * 3072;          // 96 KiB
 constexpr int PIECES = US * 3;                         // 1 KiB pieces per stage
 constexpr int QP = PIECES / 4;                         // pieces per wave per stage
+static_assert(QP <= US, "one staging piece per unit");
+constexpr int FAST_TAIL_BYTES = 2 * US * 3072;         // the stream prefetches two stages past the last layer
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct FastStage {
+    f32x4 st[QP];                                      // this wave's pieces of the stage in flight
+};
+
+// Exact three-way split of TWO fp32 values into packed bf16 words (low half = x0's term): w[i] = {bf16_i(x0), bf16_i(x1)}.
+// Written with explicit instructions: the compiler otherwise vectorises the subtractions into v_pk_add_f32, and
+// packed-fp32 instructions do NOT overlap with bf16 MFMAs (tools/ubench/mfma_valu.hip: 58 cycles for two) while
+// plain VALU instructions do (about five per 32-cycle MFMA).
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&w)[3]) {
+    float r0 = x0, r1 = x1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        unsigned p;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(r0), "v"(r1));
+        w[i] = p;
+        if (i < 2) {
+            float f0, f1;
+            asm("v_lshlrev_b32 %0, 16, %1" : "=v"(f0) : "v"(p));
+            asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(f1) : "v"(p));
+            asm("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(r0), "v"(f0));
+            asm("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(r1), "v"(f1));
+        }
+    }
+}
 
 // acc[jb] = bias + W . [in0 ; act(in1)] with six bf16 MFMAs per (output block, k-step).
 // in0 / in1 are fp32 blocks in accumulator layout; in1 is passed through ReLU when RELU1 (the previous layer's raw
-// outputs).  use(kb, v) is called with each in1 block as it is consumed (training: store + sign mask).
-template <int KB0, int KB1, int JB, bool RELU1, class Use>
+// outputs).  The layer walks its INPUT blocks in the outer loop, all JB accumulators advance together; `acc` must not
+// alias the inputs (callers alternate two buffers).
+//  * weights: the workgroup's shared stream (see mlp_core.h layer_mfma_lds): 4-slot LDS ring of 24 KiB stages, one
+//    staging piece written + reloaded per unit, one barrier per stage, fragments read one unit ahead, and the stream
+//    runs across layer ends (FIRST = false: stage 0 is already in LDS, stage 1 in `fs`);
+//  * activations: block kb+1 is split into its bf16 terms pair by pair BETWEEN the units of block kb, so the ~13
+//    vector instructions per pair issue in the shadow of the XDL MFMAs instead of as a 100-instruction clump.
+template <int KB0, int KB1, int JB, bool RELU1, bool FIRST>
 __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, const float *__restrict__ bias,
-                                             const f32x16 *in0, const f32x16 *in1, f32x16 *acc, char *wlds, int wid,
-                                             int lane, Use use) {
+                                             const f32x16 *in0, const f32x16 *in1, f32x16 *acc, char *wlds,
+                                             FastStage &fs, int wid, int lane) {
     constexpr int KBT = KB0 + KB1;
-    constexpr int NU = JB * KBT * 2;                    // units in this layer
-    constexpr int NP = NU * 3;                          // 1 KiB pieces
-    constexpr int NST = (NU + US - 1) / US;
+    constexpr int UK = 2 * JB;                          // units per input block
+    constexpr int NU = UK * KBT;                        // units in this layer
+    static_assert(NU % US == 0, "a layer is a whole number of stages");
     const char *gsrc = reinterpret_cast<const char *>(wbase) + (QP * wid) * 1024 + lane * 16;
     char *ldst = wlds + (QP * wid) * 1024 + lane * 16;
     const char *lsrc = wlds + lane * 16;
-    f32x4 st[QP];
-    auto gload = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < QP; ++i)
-            if ((stage + 1) * PIECES <= NP || stage * PIECES + QP * wid + i < NP)
-                st[i] = *reinterpret_cast<const f32x4 *>(gsrc + (int64_t)(stage * PIECES + i) * 1024);
+    auto gload = [&](int stage, int i) {
+        fs.st[i] = *reinterpret_cast<const f32x4 *>(gsrc + (int64_t)(stage * PIECES + i) * 1024);
     };
-    auto lwrite = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < QP; ++i)
-            *reinterpret_cast<f32x4 *>(ldst + ((stage % FSLOT) * PIECES + i) * 1024) = st[i];
+    auto lwrite = [&](int stage, int i) {
+        *reinterpret_cast<f32x4 *>(ldst + ((stage % FSLOT) * PIECES + i) * 1024) = fs.st[i];
     };
-    __syncthreads();
-    gload(0);
-    lwrite(0);
-    if (NST > 1) gload(1);
-    bf16x8 an[3];
-    bf16x8 bs[2][3];
+    auto lread = [&](int uu, int t) {
+        return *reinterpret_cast<const u32x4 *>(lsrc + (((uu / US) % FSLOT) * PIECES + (uu % US) * 3 + t) * 1024);
+    };
+    if (FIRST) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < QP; ++i) gload(0, i);
+#pragma unroll
+        for (int i = 0; i < QP; ++i) lwrite(0, i);
+#pragma unroll
+        for (int i = 0; i < QP; ++i) gload(1, i);
+        __syncthreads();
+    }
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
@@ -118,63 +143,74 @@ __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, c
             const f32x4 b = ldg4(bias + 32 * jb + 8 * q);
             acc[jb][4 * q + 0] = b[0]; acc[jb][4 * q + 1] = b[1]; acc[jb][4 * q + 2] = b[2]; acc[jb][4 * q + 3] = b[3];
         }
+    // bf16 terms of the current and the next input block: word [s][i][j] = values 8s+2j, 8s+2j+1 of the block, term i
+    unsigned cur[2][3][4], nxt[2][3][4];
+    auto block = [&](int kb) { return (kb < KB0) ? in0[kb] : in1[kb - KB0]; };
+    auto split_pairs = [&](int kb, int p0, int p1, unsigned (&dst)[2][3][4]) {
+        const f32x16 v = block(kb);
+#pragma unroll
+        for (int p = p0; p < p1; ++p) {
+            float x0 = v[2 * p], x1 = v[2 * p + 1];
+            if (RELU1 && kb >= KB0) { x0 = relu1(x0); x1 = relu1(x1); }
+            unsigned w[3];
+            split_pair(x0, x1, w);
+            dst[p >> 2][0][p & 3] = w[0]; dst[p >> 2][1][p & 3] = w[1]; dst[p >> 2][2][p & 3] = w[2];
+        }
+    };
+    split_pairs(0, 0, 8, cur);
+    u32x4 an[3];
 #pragma unroll
     for (int kb = 0; kb < KBT; ++kb) {
-        // split this input block just before use: its VALU work issues in the shadow of the previous block's MFMAs
-        f32x16 v = (kb < KB0) ? in0[kb] : in1[kb - KB0];
-        if (kb >= KB0) {
-            if (RELU1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+        for (int u = 0; u < UK; ++u) {
+            const int s = u / JB, jb = u % JB;
+            const int U = kb * UK + u;
+            const int stage = U / US, ul = U % US;
+            if (ul < QP) {                               // one staging piece per unit
+                lwrite(stage + 1, ul);
+                gload(stage + 2, ul);
             }
-            use(kb - KB0, v);
+            if (ul == QP) __syncthreads();               // publishes stage+1, protects the slot stage+2 will take
+            if (U == 0) { an[0] = lread(0, 0); an[1] = lread(0, 1); an[2] = lread(0, 2); }
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, an[0]), a2 = __builtin_bit_cast(bf16x8, an[1]),
+                         a3 = __builtin_bit_cast(bf16x8, an[2]);
+            if (U + 1 < NU) { an[0] = lread(U + 1, 0); an[1] = lread(U + 1, 1); an[2] = lread(U + 1, 2); }
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, u32x4{cur[s][0][0], cur[s][0][1], cur[s][0][2], cur[s][0][3]});
+            const bf16x8 b2 = __builtin_bit_cast(bf16x8, u32x4{cur[s][1][0], cur[s][1][1], cur[s][1][2], cur[s][1][3]});
+            const bf16x8 b3 = __builtin_bit_cast(bf16x8, u32x4{cur[s][2][0], cur[s][2][1], cur[s][2][2], cur[s][2][3]});
+            f32x16 c = acc[jb];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, c, 0, 0, 0);      // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+            acc[jb] = c;
+            // the next input block's split, 8 pairs spread over this block's UK units
+            if (kb + 1 < KBT) split_pairs(kb + 1, (u * 8) / UK, ((u + 1) * 8) / UK, nxt);
+            // keep every unit's staging piece, fragment reads and split pair WITH its six MFMAs: left alone the
+            // scheduler bunches the staging of a whole stage and the split of a whole block together, and a clump
+            // of more than ~5 vector instructions per MFMA is no longer hidden behind the matrix pipe
+            // ... and inside the unit: next unit's fragment reads first (a whole unit of MFMAs to land), then the
+            // staging piece, then MFMAs with the vector work dealt out between them
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);       // DS read
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // DS write
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // VMEM read
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-#ifdef FX_NOSPLIT
-        if (kb == 0) split_block(v, bs);
-#else
-        split_block(v, bs);
-#endif
+        if (kb + 1 < KBT) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int jb = 0; jb < JB; ++jb) {
-                const int U = (kb * 2 + s) * JB + jb;
-                const int stage = U / US, ul = U % US;
-                // Stage boundary: stage+1 goes to LDS, stage+2's loads are issued -- and NO barrier here.  The one
-                // barrier per stage sits in the MIDDLE of the stage: it publishes the slot written at this
-                // boundary (needed only at the next boundary) and protects the slot the next boundary will
-                // overwrite (last read in stage-1, which every wave has left by then).  Crossing a boundary
-                // therefore never drains the matrix pipe: the next stage's fragments are already visible and
-                // can be read ahead.
-                if (ul == 0) {
-#ifndef FX_NOSTREAM
-                    if (stage + 1 < NST) lwrite(stage + 1);
-                    if (stage + 2 < NST) gload(stage + 2);
-#endif
-                    if (stage == 0) __syncthreads();            // first stage of the layer: written just above
-                }
-#ifndef FX_NOBAR
-                if (ul == US / 2 && NST > 1) __syncthreads();
-#endif
-                // weight fragments are read one unit ahead (two register sets), so a unit's LDS latency hides
-                // behind the previous unit's six MFMAs
-                auto lread = [&](int uu, int t) {
-                    return *reinterpret_cast<const bf16x8 *>(lsrc + (((uu / US) % FSLOT) * PIECES + (uu % US) * 3 + t) * 1024);
-                };
-                if (U == 0) { an[0] = lread(0, 0); an[1] = lread(0, 1); an[2] = lread(0, 2); }
-                const bf16x8 a1 = an[0], a2 = an[1], a3 = an[2];
-#ifndef FX_NOLDSR
-                if (U + 1 < NU) { an[0] = lread(U + 1, 0); an[1] = lread(U + 1, 1); an[2] = lread(U + 1, 2); }
-#endif
-                f32x16 c = acc[jb];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bs[s][0], c, 0, 0, 0);      // small terms first
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[s][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bs[s][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bs[s][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[s][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[s][0], c, 0, 0, 0);
-                acc[jb] = c;
-            }
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) cur[a][b][d] = nxt[a][b][d];
+        }
     }
 }
 
@@ -254,55 +290,51 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
     embed_xyz_blocks_f(x, y, w, half, e);
     const float *bias = packed + OFF_BIAS + 4 * half;
     auto img = [&](int off) { return fast + (int64_t)(off / 512) * 1536; };      // unit * 3 pieces * 512 bf16
-    auto nouse = [](int, const f32x16 &) {};
-    f32x16 h[8], acc[8];
-    auto copy8 = [&]() {
-#pragma unroll
-        for (int b = 0; b < 8; ++b) h[b] = acc[b];
-    };
+    f32x16 hA[8], hB[8];                                 // alternate: a layer reads one, accumulates into the other
+    FastStage fs;
     NERFMI_TSF(1);
-    layer_bf16x3<2, 0, 8, false>(img(OFF_L1), bias, e, nullptr, acc, wlds, wid, lane, nouse);
-    copy8();
+    layer_bf16x3<2, 0, 8, false, true>(img(OFF_L1), bias, e, nullptr, hA, wlds, fs, wid, lane);
     NERFMI_TSF(2);
-    for (int l = 1; l <= 3; ++l) {
-        layer_bf16x3<0, 8, 8, true>(img(OFF_L2 + (l - 1) * SZ_HID), bias + 256 * l, nullptr, h, acc, wlds, wid, lane, nouse);
-        copy8();
-        NERFMI_TSF(2 + l);
-    }
-    layer_bf16x3<2, 8, 8, true>(img(OFF_L5), bias + 256 * 4, e, h, acc, wlds, wid, lane, nouse);
-    copy8();
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L2), bias + 256 * 1, nullptr, hA, hB, wlds, fs, wid, lane);
+    NERFMI_TSF(3);
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L3), bias + 256 * 2, nullptr, hB, hA, wlds, fs, wid, lane);
+    NERFMI_TSF(4);
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L4), bias + 256 * 3, nullptr, hA, hB, wlds, fs, wid, lane);
+    NERFMI_TSF(5);
+    layer_bf16x3<2, 8, 8, true, false>(img(OFF_L5), bias + 256 * 4, e, hB, hA, wlds, fs, wid, lane);
     NERFMI_TSF(6);
-    for (int l = 5; l <= 7; ++l) {                       // xyz_encoding_6..8
-        layer_bf16x3<0, 8, 8, true>(img(OFF_L6 + (l - 5) * SZ_HID), bias + 256 * l, nullptr, h, acc, wlds, wid, lane, nouse);
-        copy8();
-        NERFMI_TSF(2 + l);
-    }
-    // h = raw outputs of xyz_encoding_8; sigma = w_sigma . relu(h) + b (nerf.py:112)
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L6), bias + 256 * 5, nullptr, hA, hB, wlds, fs, wid, lane);
+    NERFMI_TSF(7);
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L7), bias + 256 * 6, nullptr, hB, hA, wlds, fs, wid, lane);
+    NERFMI_TSF(8);
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L8), bias + 256 * 7, nullptr, hA, hB, wlds, fs, wid, lane);
+    NERFMI_TSF(9);
+    // hB = raw outputs of xyz_encoding_8; sigma = w_sigma . relu(h) + b (nerf.py:112)
     float sigma;
     {
         f32x16 h8[8];
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h8[b][r] = fmaxf(h[b][r], 0.f);
+            for (int r = 0; r < 16; ++r) h8[b][r] = relu1(hB[b][r]);
         sigma = dot_blocks<8>(h8, packed + OFF_W_SIGMA + 4 * half) + packed[OFF_B_SIGMA];
     }
     if (SIGMA_ONLY) {
         if (ok && half == 0) out[p] = sigma;
         return;
     }
-    layer_bf16x3<0, 8, 8, true>(img(OFF_FINAL), bias + 256 * 8, nullptr, h, acc, wlds, wid, lane, nouse);
-    copy8();                                             // xyz_encoding_final: no activation on its output
+    // xyz_encoding_final: no activation on its output
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_FINAL), bias + 256 * 8, nullptr, hB, hA, wlds, fs, wid, lane);
     NERFMI_TSF(10);
     f32x16 de[1], dh[4];
     embed_dir_block_f(rr[3], rr[4], rr[5], half, de[0]);
     // dir_encoding input = [final (no ReLU) | dir embedding]: the packed order is final first (mlp_layout.h)
-    layer_bf16x3<8, 1, 4, false>(img(OFF_DIR), packed + OFF_BIAS_DIR + 4 * half, h, de, dh, wlds, wid, lane, nouse);
+    layer_bf16x3<8, 1, 4, false, false>(img(OFF_DIR), packed + OFF_BIAS_DIR + 4 * half, hA, de, dh, wlds, fs, wid, lane);
     NERFMI_TSF(11);
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dh[b][r] = fmaxf(dh[b][r], 0.f);
+        for (int r = 0; r < 16; ++r) dh[b][r] = relu1(dh[b][r]);
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -329,7 +361,7 @@ int nerfmi_debug_timing_fast(unsigned long long *host) {
 }
 #endif
 
-size_t nerfmi_nerf_fast_bytes(void) { return (size_t)(OFF_SMALL / 512) * 3072; }
+size_t nerfmi_nerf_fast_bytes(void) { return (size_t)(OFF_SMALL / 512) * 3072 + FAST_TAIL_BYTES; }
 
 int nerfmi_nerf_pack_fast(const float *packed, void *fast, nerfmi_stream_t stream) {
     NERFMI_REQUIRE(packed && fast, "nerf_pack_fast: null pointer");

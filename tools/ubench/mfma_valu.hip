@@ -36,6 +36,13 @@ __global__ void __launch_bounds__(256) k(float *out, unsigned long long *ts, int
                 if (KIND == 2) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(y) : "v"(b), "s"(__builtin_amdgcn_read_exec()));
                 if (KIND == 3) asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(y) : "v"(b));
                 if (KIND == 5) asm volatile("s_nop 0");
+                if (KIND == 11) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(y) : "v"(b));
+                if (KIND == 12) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(y));
+                if (KIND == 13) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(y) : "v"(b));
+                if (KIND == 14) asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(y));
+                if (KIND == 15) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(y) : "v"(b), "v"(a));
+                if (KIND == 16) asm volatile("v_accvgpr_read_b32 %0, a5" : "=v"(y));
+                if (KIND == 17) asm volatile("v_max_i32 %0, 0, %0" : "+v"(y));
                 if (KIND == 7) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[(u * V + v) % 4]) : "v"(laddr));
                 if (KIND == 8) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[(u * V + v) % 4]) : "v"(gaddr));
                 if (KIND == 9) asm volatile("ds_write_b128 %0, %1" : : "v"(laddr), "v"(ld[0]));
@@ -88,6 +95,14 @@ int main() {
     run<0, 0, 3>("v_fma_f32"); run<0, 1, 3>("v_fma_f32"); run<0, 2, 3>("v_fma_f32"); run<0, 4, 3>("v_fma_f32"); run<0, 6, 3>("v_fma_f32"); run<0, 8, 3>("v_fma_f32"); run<0, 12, 3>("v_fma_f32");
     printf("bf16 32x32x16 MFMA, two chains:\n");
     run<0, 0, 4>("v_fma_f32"); run<0, 1, 4>("v_fma_f32"); run<0, 2, 4>("v_fma_f32"); run<0, 4, 4>("v_fma_f32"); run<0, 6, 4>("v_fma_f32"); run<0, 8, 4>("v_fma_f32"); run<0, 12, 4>("v_fma_f32");
+    printf("bf16 one chain + instruction kinds (V = 2, 4, 6):\n");
+    run<11, 2, 3>("v_cvt_pk_bf16"); run<11, 4, 3>("v_cvt_pk_bf16"); run<11, 6, 3>("v_cvt_pk_bf16");
+    run<12, 2, 3>("v_and_b32 lit"); run<12, 4, 3>("v_and_b32 lit"); run<12, 6, 3>("v_and_b32 lit");
+    run<13, 2, 3>("v_sub_f32"); run<13, 4, 3>("v_sub_f32"); run<13, 6, 3>("v_sub_f32");
+    run<14, 2, 3>("v_lshlrev_b32"); run<14, 4, 3>("v_lshlrev_b32"); run<14, 6, 3>("v_lshlrev_b32");
+    run<15, 2, 3>("v_perm_b32"); run<15, 4, 3>("v_perm_b32"); run<15, 6, 3>("v_perm_b32");
+    run<16, 2, 3>("v_accvgpr_read"); run<16, 4, 3>("v_accvgpr_read"); run<16, 6, 3>("v_accvgpr_read");
+    run<17, 2, 3>("v_max_i32"); run<17, 4, 3>("v_max_i32"); run<17, 6, 3>("v_max_i32");
     printf("bf16, cvt_pk / dpp kinds, one chain:\n");
     run<1, 2, 3>("v_mov_dpp"); run<1, 4, 3>("v_mov_dpp"); run<1, 6, 3>("v_mov_dpp"); run<4, 2, 3>("v_pk_add_f32"); run<4, 4, 3>("v_pk_add_f32"); run<4, 6, 3>("v_pk_add_f32");
     return 0;
