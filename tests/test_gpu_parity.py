@@ -923,3 +923,38 @@ def test_sigma_grid_and_vol_packing(dev, models):
     same = vol == vol_ref
     assert same[0::2].all()
     assert (np.abs(vol[1::2].astype(np.int64) - vol_ref[1::2].astype(np.int64)) <= 1).all() and same.mean() > 0.99
+
+
+# --------------------------------------------------------------------------- edge batches
+def test_render_rays_edge_batches(dev, models):
+    """Empty and single-ray batches (inference and training), and the 8-GPU config's per-rank batch (C3, 8192 rays =
+    1.57 M field evaluations, the 32 768-ray validation chunk) through the same launches."""
+    from nerf_siren_amd import Embedding, NeRF, render_rays
+    params, ms = models
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    rays = T(synth.blender_rays(8192, 12), dev)
+    with torch.no_grad():
+        r0 = render_rays(ms, emb, rays[:0], 64, False, 0, 0, 64, 1024 * 32, True, False)
+        assert r0["rgb_fine"].shape == (0, 3) and r0["depth_fine"].shape == (0,) and r0["opacity_coarse"].shape == (0,)
+        big = render_rays(ms, emb, rays, 64, False, 0, 0, 64, 1024 * 32, True, True)
+        one = render_rays(ms, emb, rays[4321:4322], 64, False, 0, 0, 64, 1024 * 32, True, True)
+        for k in big:
+            assert torch.isfinite(big[k]).all()
+            assert torch.equal(one[k], big[k][4321:4322]), k
+        chunk = render_rays(ms, emb, rays.repeat(4, 1), 64, False, 0, 0, 64, 1024 * 32, True, True)
+        for k in big:
+            assert torch.equal(chunk[k][8192:16384], big[k]), k
+    # training on one ray and on an odd batch: finite gradients for every parameter, none for an empty batch
+    tr = []
+    for p in params:
+        m = NeRF()
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+        tr.append(m.to(dev))
+    for n in (1, 33):
+        for m in tr:
+            m.zero_grad(set_to_none=True)
+        res = render_rays(tr, emb, rays[:n], 64, False, 1.0, 1.0, 64, 1024 * 32, True, False)
+        (res["rgb_coarse"].square().mean() + res["rgb_fine"].square().mean()).backward()
+        for m in tr:
+            for name, q in m.named_parameters():
+                assert q.grad is not None and torch.isfinite(q.grad).all(), name
