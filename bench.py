@@ -114,8 +114,8 @@ def main():
 
     B = args.batch
     if args.math != "fp32":
-        if args.mode != "infer" or args.field != "nerf":
-            raise SystemExit("--math bf16x3 applies to --mode infer --field nerf")
+        if args.field != "nerf":
+            raise SystemExit("--math bf16x3 applies to --field nerf")
         import nerf_siren_amd
         nerf_siren_amd.set_math(args.math)
     models = []
@@ -170,12 +170,12 @@ def main():
     if args.math == "bf16x3":
         orig_fast = ops.nerf_forward_rays_fast
 
-        def timed_fast(packed, fast, rays, z, sigma_only=False):
+        def timed_fast(packed, fast, rays, z, sigma_only=False, save=False):
             if z.shape[1] != 128:
-                return orig_fast(packed, fast, rays, z, sigma_only)
+                return orig_fast(packed, fast, rays, z, sigma_only, save)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            out = orig_fast(packed, fast, rays, z, sigma_only)
+            out = orig_fast(packed, fast, rays, z, sigma_only, save)
             b.record()
             ev.append((a, b))
             return out

@@ -73,11 +73,13 @@ int nerfmi_nerf_forward_rays(const float *packed, const float *rays, const float
 /* OPT-IN fast math for the same forward (inference): every fp32 product is formed on the bf16 matrix cores
  * from exact three-way bf16 splits of both operands (six v_mfma_f32_32x32x16_bf16 per fp32-equivalent
  * product block, fp32 accumulation; dropped terms <= 2^-24 relative), 2.7x the fp32-MFMA rate at fp32-level
- * accuracy.  `fast` (nerfmi_nerf_fast_bytes() bytes) is derived from `packed` by nerfmi_nerf_pack_fast. */
+ * accuracy.  `fast` (nerfmi_nerf_fast_bytes() bytes) is derived from `packed` by nerfmi_nerf_pack_fast.
+ * saved: as in nerfmi_nerf_forward_rays (NULL for inference; same images, consumed by nerfmi_nerf_backward_rays). */
 size_t nerfmi_nerf_fast_bytes(void);
 int nerfmi_nerf_pack_fast(const float *packed, void *fast, nerfmi_stream_t stream);
 int nerfmi_nerf_forward_rays_fast(const float *packed, const void *fast, const float *rays, const float *z,
-                                  int n_rays, int n_per_ray, int sigma_only, float *out, nerfmi_stream_t stream);
+                                  int n_rays, int n_per_ray, int sigma_only, float *out, float *saved,
+                                  nerfmi_stream_t stream);
 
 /* NeRF.forward(x, sigma_only) on pre-embedded rows x (n, 90) / (n, 63)
  * (nerf.py:83-124) -- the module-level API (dense grid queries,

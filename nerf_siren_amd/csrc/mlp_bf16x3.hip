@@ -106,10 +106,17 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&w)[3])
 //    runs across layer ends (FIRST = false: stage 0 is already in LDS, stage 1 in `fs`);
 //  * activations: block kb+1 is split into its bf16 terms pair by pair BETWEEN the units of block kb, so the ~13
 //    vector instructions per pair issue in the shadow of the XDL MFMAs instead of as a 100-instruction clump.
-template <int KB0, int KB1, int JB, bool RELU1, bool FIRST>
+//  * hooks: pre0(kb, p, x0, x1) / pre1(kb, p, x0, x1) see each PAIR of values (registers 2p, 2p+1) of an in0 / in1
+//    block as it is consumed -- after the ReLU for in1 -- and may change them (backward: ReLU mask) and store them
+//    (training: the saved activation images are written here, in the shadow of the MFMAs, not in an epilogue).
+struct NoHook {
+    __device__ __forceinline__ void operator()(int, int, float &, float &) const {}
+};
+
+template <int KB0, int KB1, int JB, bool RELU1, bool FIRST, class Pre0 = NoHook, class Pre1 = NoHook>
 __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, const float *__restrict__ bias,
                                              const f32x16 *in0, const f32x16 *in1, f32x16 *acc, char *wlds,
-                                             FastStage &fs, int wid, int lane) {
+                                             FastStage &fs, int wid, int lane, Pre0 pre0 = Pre0(), Pre1 pre1 = Pre1()) {
     constexpr int KBT = KB0 + KB1;
     constexpr int UK = 2 * JB;                          // units per input block
     constexpr int NU = UK * KBT;                        // units in this layer
@@ -140,7 +147,7 @@ __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, c
     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 b = ldg4(bias + 32 * jb + 8 * q);
+            const f32x4 b = bias ? ldg4(bias + 32 * jb + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
             acc[jb][4 * q + 0] = b[0]; acc[jb][4 * q + 1] = b[1]; acc[jb][4 * q + 2] = b[2]; acc[jb][4 * q + 3] = b[3];
         }
     // bf16 terms of the current and the next input block: word [s][i][j] = values 8s+2j, 8s+2j+1 of the block, term i
@@ -152,6 +159,8 @@ __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, c
         for (int p = p0; p < p1; ++p) {
             float x0 = v[2 * p], x1 = v[2 * p + 1];
             if (RELU1 && kb >= KB0) { x0 = relu1(x0); x1 = relu1(x1); }
+            if (kb < KB0) pre0(kb, p, x0, x1);
+            else pre1(kb - KB0, p, x0, x1);
             unsigned w[3];
             split_pair(x0, x1, w);
             dst[p >> 2][0][p & 3] = w[0]; dst[p >> 2][1][p & 3] = w[1]; dst[p >> 2][2][p & 3] = w[2];
@@ -269,11 +278,11 @@ __device__ unsigned long long nerfmi_dbg_ts_fast[64 * 16];
 #define NERFMI_TSF(i) do { } while (0)
 #endif
 
-template <bool SIGMA_ONLY>
+template <bool SIGMA_ONLY, bool SAVE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__restrict__ fast,
                            const float *__restrict__ rays, const float *__restrict__ z, int64_t n_points,
-                           int n_per_ray, float *__restrict__ out) {
+                           int n_per_ray, float *__restrict__ out, float *__restrict__ saved, int64_t ld) {
     extern __shared__ __attribute__((aligned(16))) char wlds[];
     const int lane = threadIdx.x & 63, half = lane >> 5, wid = threadIdx.x >> 6;
     NERFMI_TSF(0);
@@ -281,6 +290,8 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
     const int64_t praw = wave * 32 + (lane & 31);
     const bool ok = praw < n_points;
     const int64_t p = ok ? praw : n_points - 1;
+    RowImage S;
+    S.init(saved, wave, ld / 32, SAVED_ROWS, lane, ok, wave * 32 < n_points);
     const float *rr = rays + (p / n_per_ray) * 8;
     const float zz = z[p];
     const float x = __fadd_rn(rr[0], __fmul_rn(rr[3], zz));
@@ -288,26 +299,64 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
     const float w = __fadd_rn(rr[2], __fmul_rn(rr[5], zz));
     f32x16 e[2];
     embed_xyz_blocks_f(x, y, w, half, e);
+    if (SAVE) {
+        store_block(S, S_EMB, e[0]);
+        store_block(S, S_EMB + 32, e[1]);
+    }
     const float *bias = packed + OFF_BIAS + 4 * half;
     auto img = [&](int off) { return fast + (int64_t)(off / 512) * 1536; };      // unit * 3 pieces * 512 bf16
     f32x16 hA[8], hB[8];                                 // alternate: a layer reads one, accumulates into the other
     FastStage fs;
+    // Training: a layer's post-ReLU output is written to the saved image (and its sign bits to the mask words) by
+    // the layer that CONSUMES it, pair by pair between its MFMAs (mlp_layout.h S_H / S_MASK; same images as mlp.hip).
+    unsigned mk[4] = {0u, 0u, 0u, 0u};
+    auto save_h = [&](int row0) {
+        return [&S, &mk, row0](int kb, int pr, float &x0, float &x1) {
+            if (!SAVE) return;
+            const int r = 2 * pr;
+            float *dst = S.tile + (row0 + 32 * kb + 8 * (r >> 2) + 4 * (S.lane >> 5) + (r & 3)) * 32 + (S.lane & 31);
+            __builtin_nontemporal_store(x0, dst);
+            __builtin_nontemporal_store(x1, dst + 32);
+            unsigned one;
+            asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(x0));
+            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(mk[kb >> 1]) : "v"(one), "s"(16 * (kb & 1) + r));
+            asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(x1));
+            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(mk[kb >> 1]) : "v"(one), "s"(16 * (kb & 1) + r + 1));
+        };
+    };
+    auto save_raw = [&](int row0) {                      // no activation: values only
+        return [&S, row0](int kb, int pr, float &x0, float &x1) {
+            if (!SAVE) return;
+            const int r = 2 * pr;
+            float *dst = S.tile + (row0 + 32 * kb + 8 * (r >> 2) + 4 * (S.lane >> 5) + (r & 3)) * 32 + (S.lane & 31);
+            __builtin_nontemporal_store(x0, dst);
+            __builtin_nontemporal_store(x1, dst + 32);
+        };
+    };
+    NoHook none;
     NERFMI_TSF(1);
     layer_bf16x3<2, 0, 8, false, true>(img(OFF_L1), bias, e, nullptr, hA, wlds, fs, wid, lane);
     NERFMI_TSF(2);
-    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L2), bias + 256 * 1, nullptr, hA, hB, wlds, fs, wid, lane);
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L2), bias + 256 * 1, nullptr, hA, hB, wlds, fs, wid, lane, none, save_h(S_H));
+    if (SAVE) store_mask(S, 0, mk);
     NERFMI_TSF(3);
-    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L3), bias + 256 * 2, nullptr, hB, hA, wlds, fs, wid, lane);
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L3), bias + 256 * 2, nullptr, hB, hA, wlds, fs, wid, lane, none, save_h(S_H + 256));
+    if (SAVE) store_mask(S, 1, mk);
     NERFMI_TSF(4);
-    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L4), bias + 256 * 3, nullptr, hA, hB, wlds, fs, wid, lane);
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L4), bias + 256 * 3, nullptr, hA, hB, wlds, fs, wid, lane, none, save_h(S_H + 256 * 2));
+    if (SAVE) store_mask(S, 2, mk);
     NERFMI_TSF(5);
-    layer_bf16x3<2, 8, 8, true, false>(img(OFF_L5), bias + 256 * 4, e, hB, hA, wlds, fs, wid, lane);
+    layer_bf16x3<2, 8, 8, true, false>(img(OFF_L5), bias + 256 * 4, e, hB, hA, wlds, fs, wid, lane, none, save_h(S_H + 256 * 3));
+    if (SAVE) store_mask(S, 3, mk);
     NERFMI_TSF(6);
-    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L6), bias + 256 * 5, nullptr, hA, hB, wlds, fs, wid, lane);
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L6), bias + 256 * 5, nullptr, hA, hB, wlds, fs, wid, lane, none, save_h(S_H + 256 * 4));
+    if (SAVE) store_mask(S, 4, mk);
     NERFMI_TSF(7);
-    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L7), bias + 256 * 6, nullptr, hB, hA, wlds, fs, wid, lane);
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L7), bias + 256 * 6, nullptr, hB, hA, wlds, fs, wid, lane, none, save_h(S_H + 256 * 5));
+    if (SAVE) store_mask(S, 5, mk);
     NERFMI_TSF(8);
-    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L8), bias + 256 * 7, nullptr, hA, hB, wlds, fs, wid, lane);
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_L8), bias + 256 * 7, nullptr, hA, hB, wlds, fs, wid, lane, none, save_h(S_H + 256 * 6));
+    if (SAVE) store_mask(S, 6, mk);
     NERFMI_TSF(9);
     // hB = raw outputs of xyz_encoding_8; sigma = w_sigma . relu(h) + b (nerf.py:112)
     float sigma;
@@ -324,17 +373,27 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
         return;
     }
     // xyz_encoding_final: no activation on its output
-    layer_bf16x3<0, 8, 8, true, false>(img(OFF_FINAL), bias + 256 * 8, nullptr, hB, hA, wlds, fs, wid, lane);
+    layer_bf16x3<0, 8, 8, true, false>(img(OFF_FINAL), bias + 256 * 8, nullptr, hB, hA, wlds, fs, wid, lane, none, save_h(S_H + 256 * 7));
+    if (SAVE) store_mask(S, 7, mk);
     NERFMI_TSF(10);
     f32x16 de[1], dh[4];
-    embed_dir_block_f(rr[3], rr[4], rr[5], half, de[0]);
+    embed_dir_block_f(rr[3], rr[4], rr[5], half, de[0]);    // computed here, not up front: 16 registers fewer held
+    if (SAVE) store_block(S, S_DEMB, de[0]);
     // dir_encoding input = [final (no ReLU) | dir embedding]: the packed order is final first (mlp_layout.h)
-    layer_bf16x3<8, 1, 4, false, false>(img(OFF_DIR), packed + OFF_BIAS_DIR + 4 * half, hA, de, dh, wlds, fs, wid, lane);
+    layer_bf16x3<8, 1, 4, false, false>(img(OFF_DIR), packed + OFF_BIAS_DIR + 4 * half, hA, de, dh, wlds, fs, wid, lane, save_raw(S_FINAL));
     NERFMI_TSF(11);
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < 4; ++b) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[b][r] = relu1(dh[b][r]);
+        if (SAVE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                mask_or(mk, b, q, f32x4{dh[b][4 * q], dh[b][4 * q + 1], dh[b][4 * q + 2], dh[b][4 * q + 3]});
+            store_block(S, S_DIRH + 32 * b, dh[b]);
+        }
+    }
+    if (SAVE) store_mask(S, 8, mk);
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -345,6 +404,11 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
         float4 o;
         o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2]; o.w = sigma;
         reinterpret_cast<float4 *>(out)[p] = o;
+    }
+    if (SAVE && half == 0) {
+        *S.at(S_RGB + 0) = rgb[0];
+        *S.at(S_RGB + 1) = rgb[1];
+        *S.at(S_RGB + 2) = rgb[2];
     }
     NERFMI_TSF(12);
 }
@@ -370,33 +434,38 @@ int nerfmi_nerf_pack_fast(const float *packed, void *fast, nerfmi_stream_t strea
 }
 
 int nerfmi_nerf_forward_rays_fast(const float *packed, const void *fast, const float *rays, const float *z, int n_rays,
-                                  int n_per_ray, int sigma_only, float *out, nerfmi_stream_t stream) {
+                                  int n_per_ray, int sigma_only, float *out, float *saved, nerfmi_stream_t stream) {
     NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1, "nerf_forward_rays_fast: bad sizes");
     const int64_t n_points = (int64_t)n_rays * n_per_ray;
     if (n_points == 0) return NERFMI_OK;
     NERFMI_REQUIRE(packed && fast && rays && z && out, "nerf_forward_rays_fast: null pointer");
+    NERFMI_REQUIRE(!(saved && sigma_only), "nerf_forward_rays_fast: saved activations need the full (rgb,sigma) pass");
+    const void *kernels[3] = {reinterpret_cast<const void *>(nerf_forward_bf16x3_kernel<false, false>),
+                              reinterpret_cast<const void *>(nerf_forward_bf16x3_kernel<true, false>),
+                              reinterpret_cast<const void *>(nerf_forward_bf16x3_kernel<false, true>)};
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_forward_bf16x3_kernel<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_forward_bf16x3_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES);
-        if (e1 != hipSuccess || e2 != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("nerf_forward_rays_fast: cannot raise the dynamic LDS limit");
-            return NERFMI_E_LAUNCH;
-        }
+        for (const void *k : kernels)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("nerf_forward_rays_fast: cannot raise the dynamic LDS limit");
+                return NERFMI_E_LAUNCH;
+            }
         attr_set = true;
     }
     const int64_t waves = (n_points + 31) / 32;
+    const int64_t ld = waves * 32;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (sigma_only)
-        hipLaunchKernelGGL((nerf_forward_bf16x3_kernel<true>), grid, block, FLDS_BYTES, st, packed, (const __bf16 *)fast,
-                           rays, z, n_points, n_per_ray, out);
+        hipLaunchKernelGGL((nerf_forward_bf16x3_kernel<true, false>), grid, block, FLDS_BYTES, st, packed,
+                           (const __bf16 *)fast, rays, z, n_points, n_per_ray, out, nullptr, ld);
+    else if (saved)
+        hipLaunchKernelGGL((nerf_forward_bf16x3_kernel<false, true>), grid, block, FLDS_BYTES, st, packed,
+                           (const __bf16 *)fast, rays, z, n_points, n_per_ray, out, saved, ld);
     else
-        hipLaunchKernelGGL((nerf_forward_bf16x3_kernel<false>), grid, block, FLDS_BYTES, st, packed, (const __bf16 *)fast,
-                           rays, z, n_points, n_per_ray, out);
+        hipLaunchKernelGGL((nerf_forward_bf16x3_kernel<false, false>), grid, block, FLDS_BYTES, st, packed,
+                           (const __bf16 *)fast, rays, z, n_points, n_per_ray, out, nullptr, ld);
     return check_launch("nerf_forward_rays_fast");
 }
 

@@ -129,15 +129,16 @@ def nerf_pack_fast(packed):
     return out
 
 
-def nerf_forward_rays_fast(packed, fast, rays, z, sigma_only=False):
+def nerf_forward_rays_fast(packed, fast, rays, z, sigma_only=False, save=False):
     rays = _req(rays, "rays", (None, 8))
     z = _req(z, "z", (rays.shape[0], None))
     n, p = z.shape
     out = torch.empty((n * p, 1 if sigma_only else 4), device=rays.device, dtype=torch.float32)
+    saved = torch.empty(nerf_saved_floats(n * p), device=rays.device, dtype=torch.float32) if save else None
     check(_lib.lib().nerfmi_nerf_forward_rays_fast(ptr(packed), ptr(fast), ptr(rays), ptr(z), n, p,
-                                                   int(bool(sigma_only)), ptr(out), _stream(rays)),
+                                                   int(bool(sigma_only)), ptr(out), ptr(saved), _stream(rays)),
           "nerf_forward_rays_fast")
-    return out
+    return (out, saved) if save else out
 
 
 def nerf_forward_embedded(packed, x, sigma_only=False):

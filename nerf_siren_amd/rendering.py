@@ -21,8 +21,9 @@ _MATH = "fp32"
 
 
 def set_math(mode: str):
-    """Arithmetic of the MLP matrix products in inference: 'fp32' (default, exact fp32 MFMA) or 'bf16x3'
-    (opt-in: exact three-way bf16 splits on the bf16 matrix cores, fp32-level accuracy, ~2x faster)."""
+    """Arithmetic of the MLP matrix products: 'fp32' (default, exact fp32 MFMA) or 'bf16x3' (opt-in: exact three-way
+    bf16 splits on the bf16 matrix cores, fp32-level accuracy): all forward passes (inference and the training
+    forward that saves activations); the backward kernels stay on the fp32 MFMA."""
     global _MATH
     if mode not in ("fp32", "bf16x3"):
         raise ValueError("math mode must be 'fp32' or 'bf16x3'")
@@ -53,7 +54,10 @@ class FieldRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays, z, noise, noise_std, white_back, *params):
         packed = model.packed()
-        field, saved = ops.nerf_forward_rays(packed, rays, z, sigma_only=False, save=True)
+        if _MATH == "bf16x3":
+            field, saved = ops.nerf_forward_rays_fast(packed, model.packed_fast(), rays, z, sigma_only=False, save=True)
+        else:
+            field, saved = ops.nerf_forward_rays(packed, rays, z, sigma_only=False, save=True)
         weights, rgb, depth, opacity = ops.composite(field, z, rays, noise, noise_std, white_back)
         ctx.save_for_backward(rays, z, noise if noise is not None else rays.new_empty(0), field, saved, packed)
         ctx.cfg = (noise is not None, float(noise_std), bool(white_back))

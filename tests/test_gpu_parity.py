@@ -338,15 +338,20 @@ def test_render_rays_full_size_properties(dev, models):
 
 
 # --------------------------------------------------------------------------- backward
+@pytest.mark.parametrize("fwd", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("n_rays,P", [(3, 64), (2, 128), (5, 24), (1, 1), (9, 37)])
-def test_nerf_backward_kernels_vs_oracle(ops, dev, models, n_rays, P):
+def test_nerf_backward_kernels_vs_oracle(ops, dev, models, n_rays, P, fwd):
     """dX chain + dW GEMM + slab reduce against the oracle's manual backward on the same
-    (points, dL/d[rgb,sigma]); ragged point counts (n_points % 32 != 0)."""
+    (points, dL/d[rgb,sigma]); ragged point counts (n_points % 32 != 0).  fwd = bf16x3: the activations saved by the
+    split-bf16 forward feed the same backward."""
     params, ms = models
     rays = synth.blender_rays(n_rays, 21)
     z = np.sort(synth.hash_uniform((n_rays, P), 22) * 4 + 2, -1).astype(np.float32)
     gout = synth.hash_normal((n_rays * P, 4), 23)
-    out, saved = ops.nerf_forward_rays(ms[0].packed(), T(rays, dev), T(z, dev), save=True)
+    if fwd == "bf16x3":
+        out, saved = ops.nerf_forward_rays_fast(ms[0].packed(), ms[0].packed_fast(), T(rays, dev), T(z, dev), save=True)
+    else:
+        out, saved = ops.nerf_forward_rays(ms[0].packed(), T(rays, dev), T(z, dev), save=True)
     grads = ops.nerf_backward_rays(ms[0].packed(), T(rays, dev), T(z, dev), saved, T(gout, dev))
     xyz = O.points(rays, z).reshape(-1, 3)
     x = np.concatenate([O.embed(xyz, 10), np.repeat(O.embed(rays[:, 3:6], 4), P, 0)], -1)
@@ -363,16 +368,23 @@ def test_nerf_backward_kernels_vs_oracle(ops, dev, models, n_rays, P):
 GRAD_CASES = ["blender_train", "ndc_train", "blender_disp", "coarse_only", "odd_sizes", "blender_det"]
 
 
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", GRAD_CASES)
-def test_render_rays_training_gradients(golden, dev, models, case):
+def test_render_rays_training_gradients(golden, dev, models, case, math):
     """loss.backward() through render_rays: gradients of all 2x24 parameters against the
-    reference's autograd (golden) and the oracle."""
+    reference's autograd (golden) and the oracle.  math = bf16x3: the training forward (with saved activations) on
+    the split-bf16 path, same tolerances."""
+    import nerf_siren_amd
     g = golden("g7_" + case)
     params, ms = models
     for m in ms:
         for p in m.parameters():
             p.grad = None
-    res = _run_hip(g, dev, ms, grad=True)
+    nerf_siren_amd.set_math(math)
+    try:
+        res = _run_hip(g, dev, ms, grad=True)
+    finally:
+        nerf_siren_amd.set_math("fp32")
     t = T(g["target"], dev)
     F = int(g["F"])
     loss = ((res["rgb_coarse"] - t) ** 2).mean() + 0.1 * res["depth_coarse"].mean() + 0.3 * res["opacity_coarse"].mean()

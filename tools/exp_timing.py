@@ -29,9 +29,9 @@ if FAST:
     lib.nerfmi_nerf_pack_fast.argtypes = [vp, vp, vp]
     assert lib.nerfmi_nerf_pack_fast(packed.data_ptr(), fast.data_ptr(), None) == 0
     ff = lib.nerfmi_nerf_forward_rays_fast
-    ff.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    ff.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     ff.restype = C.c_int
-    call = lambda: ff(packed.data_ptr(), fast.data_ptr(), rays.data_ptr(), z.data_ptr(), N_RAYS, P, 0, out.data_ptr(), None)
+    call = lambda: ff(packed.data_ptr(), fast.data_ptr(), rays.data_ptr(), z.data_ptr(), N_RAYS, P, 0, out.data_ptr(), None, None)
 elif SAVE:
     lib.nerfmi_nerf_saved_floats.restype = C.c_size_t
     lib.nerfmi_nerf_saved_floats.argtypes = [C.c_int64]
