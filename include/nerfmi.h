@@ -80,6 +80,11 @@ int nerfmi_nerf_pack_fast(const float *packed, void *fast, nerfmi_stream_t strea
 int nerfmi_nerf_forward_rays_fast(const float *packed, const void *fast, const float *rays, const float *z,
                                   int n_rays, int n_per_ray, int sigma_only, float *out, float *saved,
                                   nerfmi_stream_t stream);
+/* nerfmi_nerf_backward_rays with the dX chain on the split-bf16 path (the dW GEMM and the slab reduction are the
+ * fp32 kernels); same saved / workspace buffers. */
+int nerfmi_nerf_backward_rays_fast(const float *packed, const void *fast, int n_rays, int n_per_ray, const float *saved,
+                                   const float *grad_out, float *const *grad_params, float *workspace,
+                                   nerfmi_stream_t stream);
 
 /* NeRF.forward(x, sigma_only) on pre-embedded rows x (n, 90) / (n, 63)
  * (nerf.py:83-124) -- the module-level API (dense grid queries,

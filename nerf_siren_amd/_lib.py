@@ -26,6 +26,7 @@ SIGNATURES = {
     "nerfmi_nerf_forward_rays": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _f]),
     "nerfmi_nerf_fast_bytes": (C.c_size_t, []),
     "nerfmi_nerf_pack_fast": (_i, [_f, _f, _f]),
+    "nerfmi_nerf_backward_rays_fast": (_i, [_f, _f, _i, _i, _f, _f, C.POINTER(C.c_void_p), _f, _f]),
     "nerfmi_nerf_forward_rays_fast": (_i, [_f, _f, _f, _f, _i, _i, _i, _f, _f, _f]),
     "nerfmi_nerf_forward_embedded": (_i, [_f, _f, _i64, _i, _f, _f]),
     "nerfmi_nerf_backward_workspace_floats": (C.c_size_t, [_i64]),

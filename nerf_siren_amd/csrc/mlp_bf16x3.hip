@@ -10,11 +10,10 @@
 // once per layer in registers; weights are pre-split at pack time and shared through the LDS ring.
 // The default path stays the exact-fp32 MFMA (mlp.hip); this one is selected explicitly and is held to the same
 // parity tests.
-#include "mlp_core.h"
+#include "bf16x3_core.h"
 
 namespace nerfmi {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // x = p0 + p1 + p2 exactly (each step round-to-nearest-even)
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&sp)[3]) {
@@ -31,195 +30,38 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&sp)[3]) {
 // outer loop, so each input block is split just before use and all JB accumulators advance together);
 // unit -> 3 x 1 KiB: split i at bytes (unit_base + U)*3072 + i*1024 + lane*16 (8 bf16).  Built from the fp32
 // fragment image: the lane's floats of groups 2s and 2s+1 of (jb,kb) ARE its 8 k-slots of k-step s.
-struct FastLayer { int off, JB, KB; };
-__constant__ FastLayer d_fast_layers[NL_FWD] = {
-    {OFF_L1, 8, 2}, {OFF_L2, 8, 8}, {OFF_L3, 8, 8}, {OFF_L4, 8, 8}, {OFF_L5, 8, 10},
-    {OFF_L6, 8, 8}, {OFF_L7, 8, 8}, {OFF_L8, 8, 8}, {OFF_FINAL, 8, 8}, {OFF_DIR, 4, 9}};
+struct FastLayer { int off, JB, KB, unit0; };   // float offset in `packed`, output blocks, input blocks, first fast unit
+constexpr int N_FAST_LAYERS = NL_FWD + 9;
+__constant__ FastLayer d_fast_layers[N_FAST_LAYERS] = {
+    {OFF_L1, 8, 2, OFF_L1 / 512}, {OFF_L2, 8, 8, OFF_L2 / 512}, {OFF_L3, 8, 8, OFF_L3 / 512}, {OFF_L4, 8, 8, OFF_L4 / 512},
+    {OFF_L5, 8, 10, OFF_L5 / 512}, {OFF_L6, 8, 8, OFF_L6 / 512}, {OFF_L7, 8, 8, OFF_L7 / 512}, {OFF_L8, 8, 8, OFF_L8 / 512},
+    {OFF_FINAL, 8, 8, OFF_FINAL / 512}, {OFF_DIR, 4, 9, OFF_DIR / 512},
+    // transposed images of the backward chain, in the order it walks them: (output blocks of dX, contraction blocks)
+    {OFF_TDIR, 8, 4, FAST_FWD_UNITS + (OFF_TDIR - OFF_TRANS) / 512}, {OFF_TFINAL, 8, 8, FAST_FWD_UNITS + (OFF_TFINAL - OFF_TRANS) / 512},
+    {OFF_T8, 8, 8, FAST_FWD_UNITS + (OFF_T8 - OFF_TRANS) / 512}, {OFF_T7, 8, 8, FAST_FWD_UNITS + (OFF_T7 - OFF_TRANS) / 512},
+    {OFF_T6, 8, 8, FAST_FWD_UNITS + (OFF_T6 - OFF_TRANS) / 512}, {OFF_T5, 8, 8, FAST_FWD_UNITS + (OFF_T5 - OFF_TRANS) / 512},
+    {OFF_T4, 8, 8, FAST_FWD_UNITS + (OFF_T4 - OFF_TRANS) / 512}, {OFF_T3, 8, 8, FAST_FWD_UNITS + (OFF_T3 - OFF_TRANS) / 512},
+    {OFF_T2, 8, 8, FAST_FWD_UNITS + (OFF_T2 - OFF_TRANS) / 512}};
 
 __global__ void pack_bf16x3_kernel(const float *__restrict__ packed, __bf16 *__restrict__ fast) {
-    const int n_units = OFF_SMALL / 512;
+    const int n_units = FAST_FWD_UNITS + FAST_T_UNITS;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_units * 64; idx += gridDim.x * blockDim.x) {
-        const int Usrc = idx >> 6, lane = idx & 63;          // source unit in (jb,kb,s) order
+        const int U = idx >> 6, lane = idx & 63;             // fast unit index; its layer, then its source unit (jb,kb,s)
         int li = 0;
 #pragma unroll
-        for (int l = 1; l < NL_FWD; ++l)
-            if (Usrc * 512 >= d_fast_layers[l].off) li = l;
+        for (int l = 1; l < N_FAST_LAYERS; ++l)
+            if (U >= d_fast_layers[l].unit0) li = l;
         const FastLayer L = d_fast_layers[li];
-        const int rel = Usrc - L.off / 512;
-        const int s = rel & 1, kb = (rel >> 1) % L.KB, jb = (rel >> 1) / L.KB;
-        const int Udst = L.off / 512 + (kb * 2 + s) * L.JB + jb;
-        const f32x4 v0 = ldg4(packed + (int64_t)Usrc * 512 + lane * 4), v1 = ldg4(packed + (int64_t)Usrc * 512 + 256 + lane * 4);
+        const int rel = U - L.unit0;                         // destination order: (kb*2 + s)*JB + jb
+        const int jb = rel % L.JB, s = (rel / L.JB) & 1, kb = rel / (2 * L.JB);
+        const float *src = packed + L.off + (int64_t)((jb * L.KB + kb) * 2 + s) * 512;
+        const f32x4 v0 = ldg4(src + lane * 4), v1 = ldg4(src + 256 + lane * 4);
         const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         bf16x8 sp[3];
         split8(x, sp);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            *reinterpret_cast<bf16x8 *>(fast + ((int64_t)Udst * 3 + i) * 512 + lane * 8) = sp[i];
-    }
-}
-
-// LDS ring of stages of US units (3 KiB each)
-#ifndef NERFMI_US
-#define NERFMI_US 8
-#endif
-constexpr int US = NERFMI_US;                          // units per stage
-constexpr int FSLOT = 4;
-constexpr int FLDS_BYTES = FSLOT * US * 3072;          // 96 KiB
-constexpr int PIECES = US * 3;                         // 1 KiB pieces per stage
-constexpr int QP = PIECES / 4;                         // pieces per wave per stage
-static_assert(QP <= US, "one staging piece per unit");
-constexpr int FAST_TAIL_BYTES = 2 * US * 3072;         // the stream prefetches two stages past the last layer
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-struct FastStage {
-    f32x4 st[QP];                                      // this wave's pieces of the stage in flight
-};
-
-// Exact three-way split of TWO fp32 values into packed bf16 words (low half = x0's term): w[i] = {bf16_i(x0), bf16_i(x1)}.
-// Written with explicit instructions: the compiler otherwise vectorises the subtractions into v_pk_add_f32, and
-// packed-fp32 instructions do NOT overlap with bf16 MFMAs (tools/ubench/mfma_valu.hip: 58 cycles for two) while
-// plain VALU instructions do (about five per 32-cycle MFMA).
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&w)[3]) {
-    float r0 = x0, r1 = x1;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        unsigned p;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(r0), "v"(r1));
-        w[i] = p;
-        if (i < 2) {
-            float f0, f1;
-            asm("v_lshlrev_b32 %0, 16, %1" : "=v"(f0) : "v"(p));
-            asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(f1) : "v"(p));
-            asm("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(r0), "v"(f0));
-            asm("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(r1), "v"(f1));
-        }
-    }
-}
-
-// acc[jb] = bias + W . [in0 ; act(in1)] with six bf16 MFMAs per (output block, k-step).
-// in0 / in1 are fp32 blocks in accumulator layout; in1 is passed through ReLU when RELU1 (the previous layer's raw
-// outputs).  The layer walks its INPUT blocks in the outer loop, all JB accumulators advance together; `acc` must not
-// alias the inputs (callers alternate two buffers).
-//  * weights: the workgroup's shared stream (see mlp_core.h layer_mfma_lds): 4-slot LDS ring of 24 KiB stages, one
-//    staging piece written + reloaded per unit, one barrier per stage, fragments read one unit ahead, and the stream
-//    runs across layer ends (FIRST = false: stage 0 is already in LDS, stage 1 in `fs`);
-//  * activations: block kb+1 is split into its bf16 terms pair by pair BETWEEN the units of block kb, so the ~13
-//    vector instructions per pair issue in the shadow of the XDL MFMAs instead of as a 100-instruction clump.
-//  * hooks: pre0(kb, p, x0, x1) / pre1(kb, p, x0, x1) see each PAIR of values (registers 2p, 2p+1) of an in0 / in1
-//    block as it is consumed -- after the ReLU for in1 -- and may change them (backward: ReLU mask) and store them
-//    (training: the saved activation images are written here, in the shadow of the MFMAs, not in an epilogue).
-struct NoHook {
-    __device__ __forceinline__ void operator()(int, int, float &, float &) const {}
-};
-
-template <int KB0, int KB1, int JB, bool RELU1, bool FIRST, class Pre0 = NoHook, class Pre1 = NoHook>
-__device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, const float *__restrict__ bias,
-                                             const f32x16 *in0, const f32x16 *in1, f32x16 *acc, char *wlds,
-                                             FastStage &fs, int wid, int lane, Pre0 pre0 = Pre0(), Pre1 pre1 = Pre1()) {
-    constexpr int KBT = KB0 + KB1;
-    constexpr int UK = 2 * JB;                          // units per input block
-    constexpr int NU = UK * KBT;                        // units in this layer
-    static_assert(NU % US == 0, "a layer is a whole number of stages");
-    const char *gsrc = reinterpret_cast<const char *>(wbase) + (QP * wid) * 1024 + lane * 16;
-    char *ldst = wlds + (QP * wid) * 1024 + lane * 16;
-    const char *lsrc = wlds + lane * 16;
-    auto gload = [&](int stage, int i) {
-        fs.st[i] = *reinterpret_cast<const f32x4 *>(gsrc + (int64_t)(stage * PIECES + i) * 1024);
-    };
-    auto lwrite = [&](int stage, int i) {
-        *reinterpret_cast<f32x4 *>(ldst + ((stage % FSLOT) * PIECES + i) * 1024) = fs.st[i];
-    };
-    auto lread = [&](int uu, int t) {
-        return *reinterpret_cast<const u32x4 *>(lsrc + (((uu / US) % FSLOT) * PIECES + (uu % US) * 3 + t) * 1024);
-    };
-    if (FIRST) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < QP; ++i) gload(0, i);
-#pragma unroll
-        for (int i = 0; i < QP; ++i) lwrite(0, i);
-#pragma unroll
-        for (int i = 0; i < QP; ++i) gload(1, i);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int jb = 0; jb < JB; ++jb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = bias ? ldg4(bias + 32 * jb + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[jb][4 * q + 0] = b[0]; acc[jb][4 * q + 1] = b[1]; acc[jb][4 * q + 2] = b[2]; acc[jb][4 * q + 3] = b[3];
-        }
-    // bf16 terms of the current and the next input block: word [s][i][j] = values 8s+2j, 8s+2j+1 of the block, term i
-    unsigned cur[2][3][4], nxt[2][3][4];
-    auto block = [&](int kb) { return (kb < KB0) ? in0[kb] : in1[kb - KB0]; };
-    auto split_pairs = [&](int kb, int p0, int p1, unsigned (&dst)[2][3][4]) {
-        const f32x16 v = block(kb);
-#pragma unroll
-        for (int p = p0; p < p1; ++p) {
-            float x0 = v[2 * p], x1 = v[2 * p + 1];
-            if (RELU1 && kb >= KB0) { x0 = relu1(x0); x1 = relu1(x1); }
-            if (kb < KB0) pre0(kb, p, x0, x1);
-            else pre1(kb - KB0, p, x0, x1);
-            unsigned w[3];
-            split_pair(x0, x1, w);
-            dst[p >> 2][0][p & 3] = w[0]; dst[p >> 2][1][p & 3] = w[1]; dst[p >> 2][2][p & 3] = w[2];
-        }
-    };
-    split_pairs(0, 0, 8, cur);
-    u32x4 an[3];
-#pragma unroll
-    for (int kb = 0; kb < KBT; ++kb) {
-#pragma unroll
-        for (int u = 0; u < UK; ++u) {
-            const int s = u / JB, jb = u % JB;
-            const int U = kb * UK + u;
-            const int stage = U / US, ul = U % US;
-            if (ul < QP) {                               // one staging piece per unit
-                lwrite(stage + 1, ul);
-                gload(stage + 2, ul);
-            }
-            if (ul == QP) __syncthreads();               // publishes stage+1, protects the slot stage+2 will take
-            if (U == 0) { an[0] = lread(0, 0); an[1] = lread(0, 1); an[2] = lread(0, 2); }
-            const bf16x8 a1 = __builtin_bit_cast(bf16x8, an[0]), a2 = __builtin_bit_cast(bf16x8, an[1]),
-                         a3 = __builtin_bit_cast(bf16x8, an[2]);
-            if (U + 1 < NU) { an[0] = lread(U + 1, 0); an[1] = lread(U + 1, 1); an[2] = lread(U + 1, 2); }
-            const bf16x8 b1 = __builtin_bit_cast(bf16x8, u32x4{cur[s][0][0], cur[s][0][1], cur[s][0][2], cur[s][0][3]});
-            const bf16x8 b2 = __builtin_bit_cast(bf16x8, u32x4{cur[s][1][0], cur[s][1][1], cur[s][1][2], cur[s][1][3]});
-            const bf16x8 b3 = __builtin_bit_cast(bf16x8, u32x4{cur[s][2][0], cur[s][2][1], cur[s][2][2], cur[s][2][3]});
-            f32x16 c = acc[jb];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, c, 0, 0, 0);      // small terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
-            acc[jb] = c;
-            // the next input block's split, 8 pairs spread over this block's UK units
-            if (kb + 1 < KBT) split_pairs(kb + 1, (u * 8) / UK, ((u + 1) * 8) / UK, nxt);
-            // keep every unit's staging piece, fragment reads and split pair WITH its six MFMAs: left alone the
-            // scheduler bunches the staging of a whole stage and the split of a whole block together, and a clump
-            // of more than ~5 vector instructions per MFMA is no longer hidden behind the matrix pipe
-            // ... and inside the unit: next unit's fragment reads first (a whole unit of MFMAs to land), then the
-            // staging piece, then MFMAs with the vector work dealt out between them
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);       // DS read
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // DS write
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // VMEM read
-#pragma unroll
-            for (int m = 0; m < 6; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (kb + 1 < KBT) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b)
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) cur[a][b][d] = nxt[a][b][d];
-        }
+            *reinterpret_cast<bf16x8 *>(fast + ((int64_t)U * 3 + i) * 512 + lane * 8) = sp[i];
     }
 }
 
@@ -304,7 +146,7 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
         store_block(S, S_EMB + 32, e[1]);
     }
     const float *bias = packed + OFF_BIAS + 4 * half;
-    auto img = [&](int off) { return fast + (int64_t)(off / 512) * 1536; };      // unit * 3 pieces * 512 bf16
+    auto img = [&](int off) { return fast + fast_fwd_elems(off); };
     f32x16 hA[8], hB[8];                                 // alternate: a layer reads one, accumulates into the other
     FastStage fs;
     // Training: a layer's post-ReLU output is written to the saved image (and its sign bits to the mask words) by
@@ -425,7 +267,7 @@ int nerfmi_debug_timing_fast(unsigned long long *host) {
 }
 #endif
 
-size_t nerfmi_nerf_fast_bytes(void) { return (size_t)(OFF_SMALL / 512) * 3072 + FAST_TAIL_BYTES; }
+size_t nerfmi_nerf_fast_bytes(void) { return (size_t)(FAST_FWD_UNITS + FAST_T_UNITS) * 3072 + FAST_TAIL_BYTES; }
 
 int nerfmi_nerf_pack_fast(const float *packed, void *fast, nerfmi_stream_t stream) {
     NERFMI_REQUIRE(packed && fast, "nerf_pack_fast: null pointer");

@@ -14,7 +14,7 @@
 //     into chunks (split-K) and every workgroup writes its partial slab.
 //  3. nerf_dw_reduce_kernel -- deterministic slab reduction into the (out,in)
 //     gradient tensors (no float atomics: results are bit-reproducible).
-#include "mlp_core.h"
+#include "bf16x3_core.h"
 
 namespace nerfmi {
 
@@ -124,6 +124,113 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
     back(3, dzA, dzB);
     back(2, dzB, dzA);
     back(1, dzA, dzB);
+}
+
+// ---------------------------------------------------------------------------
+// 1b. dX chain on the bf16 matrix cores (opt-in split-bf16 math, bf16x3_core.h): same images in, same images out.
+//     A layer's raw output is finished -- ReLU-masked with the forward's sign bits, stored as the dZ image the dW GEMM
+//     reads -- by the layer that CONSUMES it, pair by pair between its MFMAs; d h8 starts from w_sigma * d sigma.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+nerf_backward_chain_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__restrict__ fast,
+                                  const float *__restrict__ saved, const float *__restrict__ grad_out, int64_t n_points,
+                                  int64_t ld, float *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char wlds_fast[];
+    const int lane = threadIdx.x & 63, half = lane >> 5, wid = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t p0 = wave * 32;
+    const bool live = p0 < n_points;
+    const int64_t praw = p0 + (lane & 31);
+    const bool ok = praw < n_points;
+    RowImage S, Wk;
+    S.init(const_cast<float *>(saved), wave, ld / 32, SAVED_ROWS, lane, ok, live);
+    Wk.init(work, wave, ld / 32, W_ROWS, lane, ok, live);
+
+    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) go = reinterpret_cast<const float4 *>(grad_out)[praw];
+    float dpre[3];
+    {
+        const float g3[3] = {go.x, go.y, go.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float rgb = *S.at(S_RGB + c);
+            dpre[c] = g3[c] * rgb * (1.0f - rgb);
+            if (half == 0) *Wk.at(W_DRGB + c) = dpre[c];
+        }
+        if (half == 0) *Wk.at(W_DSIG) = go.w;
+    }
+    const float dsig = go.w;
+
+    f32x16 dzA[8], dzB[8];
+    unsigned mk[4];
+    load_mask(S, 8, mk);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        f32x16 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 w[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w[c] = ldg4(packed + OFF_W_RGB + 128 * c + 32 * b + 8 * q + 4 * half);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float s = __builtin_fmaf(w[2][t], dpre[2], __builtin_fmaf(w[1][t], dpre[1], w[0][t] * dpre[0]));
+                v[4 * q + t] = mask_keep(mk, b, q, t, s);
+            }
+        }
+        dzA[b] = v;
+        store_block(Wk, W_DDIR + 32 * b, v);
+    }
+    FastStage fs;
+    NoHook none;
+    // consuming hooks: store the pair's rows of the dZ image at `row0`, optionally after the ReLU mask
+    auto put = [&Wk](int row0, int kb, int pr, float x0, float x1) {
+        const int r = 2 * pr;
+        float *dst = Wk.tile + (row0 + 32 * kb + 8 * (r >> 2) + 4 * (Wk.lane >> 5) + (r & 3)) * 32 + (Wk.lane & 31);
+        __builtin_nontemporal_store(x0, dst);
+        __builtin_nontemporal_store(x1, dst + 32);
+    };
+    auto plain = [&](int row0) {
+        return [&put, row0](int kb, int pr, float &x0, float &x1) { put(row0, kb, pr, x0, x1); };
+    };
+    auto masked = [&](int row0) {
+        return [&put, &mk, row0](int kb, int pr, float &x0, float &x1) {
+            const int r = 2 * pr;
+            x0 = mask_keep(mk, kb, r >> 2, r & 3, x0);
+            x1 = mask_keep(mk, kb, r >> 2, (r & 3) + 1, x1);
+            put(row0, kb, pr, x0, x1);
+        };
+    };
+    auto timg = [&](int off) { return fast + fast_t_elems(off); };
+    // d final = W_dir[:, :256]^T dZ_dir   (dZ_dir is already masked and stored above)
+    layer_bf16x3<4, 0, 8, false, true>(timg(OFF_TDIR), nullptr, dzA, nullptr, dzB, wlds_fast, fs, wid, lane);
+    // d h8 = W_final^T d final + w_sigma d sigma: consumes d final (stored as it goes, no activation on final)
+    layer_bf16x3<8, 0, 8, false, false>(timg(OFF_TFINAL), packed + OFF_W_SIGMA + 4 * half, dzB, nullptr, dzA, wlds_fast, fs,
+                                        wid, lane, plain(W_DFINAL), none, dsig);
+    // xyz_encoding_8 .. 2: the layer consuming d h_l masks it with h_l > 0 and stores it as dZ_l
+    load_mask(S, 7, mk);
+    layer_bf16x3<8, 0, 8, false, false>(timg(OFF_T8), nullptr, dzA, nullptr, dzB, wlds_fast, fs, wid, lane, masked(W_DZ + 7 * 256));
+    load_mask(S, 6, mk);
+    layer_bf16x3<8, 0, 8, false, false>(timg(OFF_T7), nullptr, dzB, nullptr, dzA, wlds_fast, fs, wid, lane, masked(W_DZ + 6 * 256));
+    load_mask(S, 5, mk);
+    layer_bf16x3<8, 0, 8, false, false>(timg(OFF_T6), nullptr, dzA, nullptr, dzB, wlds_fast, fs, wid, lane, masked(W_DZ + 5 * 256));
+    load_mask(S, 4, mk);
+    layer_bf16x3<8, 0, 8, false, false>(timg(OFF_T5), nullptr, dzB, nullptr, dzA, wlds_fast, fs, wid, lane, masked(W_DZ + 4 * 256));
+    load_mask(S, 3, mk);
+    layer_bf16x3<8, 0, 8, false, false>(timg(OFF_T4), nullptr, dzA, nullptr, dzB, wlds_fast, fs, wid, lane, masked(W_DZ + 3 * 256));
+    load_mask(S, 2, mk);
+    layer_bf16x3<8, 0, 8, false, false>(timg(OFF_T3), nullptr, dzB, nullptr, dzA, wlds_fast, fs, wid, lane, masked(W_DZ + 2 * 256));
+    load_mask(S, 1, mk);
+    layer_bf16x3<8, 0, 8, false, false>(timg(OFF_T2), nullptr, dzA, nullptr, dzB, wlds_fast, fs, wid, lane, masked(W_DZ + 1 * 256));
+    // d h1 has no consumer in the chain (the inputs carry no gradient): mask and store it here
+    load_mask(S, 0, mk);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        f32x16 v = dzB[b];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = mask_keep(mk, b, r >> 2, r & 3, v[r]);
+        store_block(Wk, W_DZ + 32 * b, v);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -391,40 +498,61 @@ size_t nerfmi_nerf_backward_workspace_floats(int64_t n_points) {
     return (size_t)W_ROWS * (size_t)(ld + 32) + plan_partial_floats(P);   // + the dump tile (mlp_core.h RowImage)
 }
 
-int nerfmi_nerf_backward_rays(const float *packed, const float *rays, const float *z, int n_rays, int n_per_ray,
-                              const float *saved, const float *grad_out, float *const *grad_params,
-                              float *workspace, nerfmi_stream_t stream) {
-    (void)rays; (void)z;   // inputs carry no gradient (rendering.py:54, :244); kept for ABI symmetry
-    NERFMI_REQUIRE(n_rays >= 1 && n_per_ray >= 1, "nerf_backward_rays: bad sizes");
-    NERFMI_REQUIRE(packed && saved && grad_out && grad_params && workspace, "nerf_backward_rays: null pointer");
+static int backward_impl(const char *who, const float *packed, const void *fast, int n_rays, int n_per_ray,
+                         const float *saved, const float *grad_out, float *const *grad_params, float *workspace,
+                         nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_rays >= 1 && n_per_ray >= 1, "%s: bad sizes", who);
+    NERFMI_REQUIRE(packed && saved && grad_out && grad_params && workspace, "%s: null pointer", who);
     const int64_t n_points = (int64_t)n_rays * n_per_ray;
     const int64_t ld = pad_points(n_points);
     GradPtrs G;
     for (int i = 0; i < N_PARAMS; ++i) {
-        NERFMI_REQUIRE(grad_params[i], "nerf_backward_rays: grad_params[%d] is null", i);
+        NERFMI_REQUIRE(grad_params[i], "%s: grad_params[%d] is null", who, i);
         G.p[i] = grad_params[i];
     }
     hipStream_t st = (hipStream_t)stream;
     float *work = workspace;
     float *partial = workspace + (size_t)W_ROWS * (ld + 32);
     const int64_t waves = (n_points + 31) / 32;
-    hipLaunchKernelGGL(nerf_backward_chain_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
-                       grad_out, n_points, ld, work);
     const DwPlan P = make_plan(ld);
     const size_t lds = sizeof(float) * 2 * 512 * LROW;  // two 73 728-B tile buffers (> the 64 KiB default dynamic-LDS limit)
     static thread_local bool lds_attr_set = false;
     if (!lds_attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
+                                (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_backward_chain_bf16x3_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess) {
             (void)hipGetLastError();
-            set_error("nerf_backward_rays: cannot raise the dynamic LDS limit to %zu bytes", lds);
+            set_error("%s: cannot raise the dynamic LDS limit", who);
             return NERFMI_E_LAUNCH;
         }
         lds_attr_set = true;
     }
+    if (fast)
+        hipLaunchKernelGGL(nerf_backward_chain_bf16x3_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), FLDS_BYTES, st,
+                           packed, (const __bf16 *)fast, saved, grad_out, n_points, ld, work);
+    else
+        hipLaunchKernelGGL(nerf_backward_chain_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
+                           grad_out, n_points, ld, work);
     hipLaunchKernelGGL(nerf_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
     hipLaunchKernelGGL(nerf_dw_reduce_kernel, dim3(128, P.n_tasks), dim3(256), 0, st, P, partial, G);
-    return check_launch("nerf_backward_rays");
+    return check_launch(who);
+}
+
+int nerfmi_nerf_backward_rays(const float *packed, const float *rays, const float *z, int n_rays, int n_per_ray,
+                              const float *saved, const float *grad_out, float *const *grad_params,
+                              float *workspace, nerfmi_stream_t stream) {
+    (void)rays; (void)z;   // inputs carry no gradient (rendering.py:54, :244); kept for ABI symmetry
+    return backward_impl("nerf_backward_rays", packed, nullptr, n_rays, n_per_ray, saved, grad_out, grad_params, workspace,
+                         stream);
+}
+
+int nerfmi_nerf_backward_rays_fast(const float *packed, const void *fast, int n_rays, int n_per_ray, const float *saved,
+                                   const float *grad_out, float *const *grad_params, float *workspace,
+                                   nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(fast, "nerf_backward_rays_fast: null pointer");
+    return backward_impl("nerf_backward_rays_fast", packed, fast, n_rays, n_per_ray, saved, grad_out, grad_params, workspace,
+                         stream);
 }
 
 }  // extern "C"

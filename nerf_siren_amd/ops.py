@@ -150,8 +150,9 @@ def nerf_forward_embedded(packed, x, sigma_only=False):
     return out
 
 
-def nerf_backward_rays(packed, rays, z, saved, grad_out, grads=None):
-    """-> list of 24 gradient tensors (PARAM_ORDER), written not accumulated."""
+def nerf_backward_rays(packed, rays, z, saved, grad_out, grads=None, fast=None):
+    """-> list of 24 gradient tensors (PARAM_ORDER), written not accumulated.
+    fast: the split-bf16 image (nerf_pack_fast) to run the dX chain on the bf16 matrix cores (opt-in math)."""
     rays = _req(rays, "rays", (None, 8))
     z = _req(z, "z", (rays.shape[0], None))
     n, p = z.shape
@@ -160,8 +161,13 @@ def nerf_backward_rays(packed, rays, z, saved, grad_out, grads=None):
         grads = flat_views(torch.empty(PARAM_NUMEL, device=rays.device, dtype=torch.float32))
     ws = torch.empty(_lib.lib().nerfmi_nerf_backward_workspace_floats(n * p), device=rays.device,
                      dtype=torch.float32)
-    check(_lib.lib().nerfmi_nerf_backward_rays(ptr(packed), ptr(rays), ptr(z), n, p, ptr(saved), ptr(grad_out),
-                                               _ptr_array(grads), ptr(ws), _stream(rays)), "nerf_backward_rays")
+    if fast is not None:
+        check(_lib.lib().nerfmi_nerf_backward_rays_fast(ptr(packed), ptr(fast), n, p, ptr(saved), ptr(grad_out),
+                                                        _ptr_array(grads), ptr(ws), _stream(rays)),
+              "nerf_backward_rays_fast")
+    else:
+        check(_lib.lib().nerfmi_nerf_backward_rays(ptr(packed), ptr(rays), ptr(z), n, p, ptr(saved), ptr(grad_out),
+                                                   _ptr_array(grads), ptr(ws), _stream(rays)), "nerf_backward_rays")
     return grads
 
 

@@ -23,7 +23,7 @@ _MATH = "fp32"
 def set_math(mode: str):
     """Arithmetic of the MLP matrix products: 'fp32' (default, exact fp32 MFMA) or 'bf16x3' (opt-in: exact three-way
     bf16 splits on the bf16 matrix cores, fp32-level accuracy): all forward passes (inference and the training
-    forward that saves activations); the backward kernels stay on the fp32 MFMA."""
+    forward that saves activations) and the backward dX chain; the dW GEMM stays on the fp32 MFMA."""
     global _MATH
     if mode not in ("fp32", "bf16x3"):
         raise ValueError("math mode must be 'fp32' or 'bf16x3'")
@@ -61,6 +61,7 @@ class FieldRender(torch.autograd.Function):
         weights, rgb, depth, opacity = ops.composite(field, z, rays, noise, noise_std, white_back)
         ctx.save_for_backward(rays, z, noise if noise is not None else rays.new_empty(0), field, saved, packed)
         ctx.cfg = (noise is not None, float(noise_std), bool(white_back))
+        ctx.fast = model.packed_fast() if _MATH == "bf16x3" else None
         ctx.mark_non_differentiable(weights)
         ctx.set_materialize_grads(False)        # absent d/d(depth, opacity) arrive as None -> NULL in the C ABI
         return rgb, depth, opacity, weights
@@ -73,7 +74,7 @@ class FieldRender(torch.autograd.Function):
             return (None,) * (6 + len(ops.PARAM_ORDER))
         grad_field = ops.composite_backward(field, z, rays, noise if has_noise else None, noise_std, white_back,
                                             g_rgb, g_depth, g_opacity)
-        grads = ops.nerf_backward_rays(packed, rays, z, saved, grad_field)
+        grads = ops.nerf_backward_rays(packed, rays, z, saved, grad_field, fast=ctx.fast)
         return (None, None, None, None, None, None, *grads)
 
 

@@ -343,7 +343,7 @@ def test_render_rays_full_size_properties(dev, models):
 def test_nerf_backward_kernels_vs_oracle(ops, dev, models, n_rays, P, fwd):
     """dX chain + dW GEMM + slab reduce against the oracle's manual backward on the same
     (points, dL/d[rgb,sigma]); ragged point counts (n_points % 32 != 0).  fwd = bf16x3: the activations saved by the
-    split-bf16 forward feed the same backward."""
+    split-bf16 forward feed the backward whose dX chain also runs on the split-bf16 path."""
     params, ms = models
     rays = synth.blender_rays(n_rays, 21)
     z = np.sort(synth.hash_uniform((n_rays, P), 22) * 4 + 2, -1).astype(np.float32)
@@ -352,7 +352,8 @@ def test_nerf_backward_kernels_vs_oracle(ops, dev, models, n_rays, P, fwd):
         out, saved = ops.nerf_forward_rays_fast(ms[0].packed(), ms[0].packed_fast(), T(rays, dev), T(z, dev), save=True)
     else:
         out, saved = ops.nerf_forward_rays(ms[0].packed(), T(rays, dev), T(z, dev), save=True)
-    grads = ops.nerf_backward_rays(ms[0].packed(), T(rays, dev), T(z, dev), saved, T(gout, dev))
+    grads = ops.nerf_backward_rays(ms[0].packed(), T(rays, dev), T(z, dev), saved, T(gout, dev),
+                                   fast=ms[0].packed_fast() if fwd == "bf16x3" else None)
     xyz = O.points(rays, z).reshape(-1, 3)
     x = np.concatenate([O.embed(xyz, 10), np.repeat(O.embed(rays[:, 3:6], 4), P, 0)], -1)
     o_ref, cache = O.nerf_forward(params[0], x, keep=True)
