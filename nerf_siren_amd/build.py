@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libnerfmi.so")
 SOURCES = ["rays.hip", "mlp.hip", "mlp_bwd.hip", "siren.hip", "eg3d.hip", "eg3d_bwd.hip", "mlp_bf16x3.hip", "train_step.hip", "raygen.hip"]
-HEADERS = ["common.h", "mlp_layout.h", "mlp_core.h", os.path.join("..", "..", "include", "nerfmi.h")]
+HEADERS = ["common.h", "mlp_layout.h", "mlp_core.h", "bf16x3_core.h", os.path.join("..", "..", "include", "nerfmi.h")]
 # -ffp-contract=off: the per-ray kernels reproduce torch's op-by-op fp32 rounding
 # (oracle/nerf_oracle.py); fused multiply-adds are written explicitly where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -37,13 +37,35 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     extra = os.environ.get("NERFMI_EXTRA_FLAGS", "").split()       # experiment builds (-D switches in csrc/)
-    cmd = [hipcc()] + FLAGS + extra + srcs + ["-o", LIB + ".tmp"]
+    cflags = [f for f in FLAGS if f != "-shared"] + extra
+    objdir = os.path.join(HERE, "lib", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        jobs.append((src, obj, [hipcc()] + cflags + ["-c", src, "-o", obj]))
+
+    def run(job):
+        src, obj, cmd = job
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return src, r
+
+    # the fully unrolled MLP kernels take minutes each: compile the translation units side by side
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+        for src, r in ex.map(run, jobs):
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n" + r.stdout + r.stderr)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [j[1] for j in jobs] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
     os.replace(LIB + ".tmp", LIB)
+    shutil.rmtree(objdir, ignore_errors=True)
     return LIB
 
 

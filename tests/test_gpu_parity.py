@@ -618,14 +618,17 @@ def test_eg3d_ray_limits_box_and_auto(golden, dev, osg):
 
 
 # --------------------------------------------------------------------------- PSNR parity (metric: "+ PSNR")
-@pytest.mark.parametrize("impl", ["torch", "fused"])
+@pytest.mark.parametrize("impl", ["torch", "fused", "fused+bf16x3"])
 def test_psnr_parity(golden, dev, impl):
-    """impl: torch.optim.Adam + elementwise loss, or training.FusedAdam + FusedMSELoss (one launch each).
+    """impl: torch.optim.Adam + elementwise loss, or training.FusedAdam + FusedMSELoss (one launch each), or the latter
+    with the opt-in split-bf16 math for the forward passes and the dX chain.
     Teacher-scene protocol: the same 240 Adam steps the reference ran on CPU
     (tools/make_psnr_golden.py: same teacher images, same batches, same injected random draws, same
     initial weights, Adam lr 5e-4) on the HIP path; validation PSNR must agree within 0.1 dB (north_star)."""
+    import nerf_siren_amd
     from nerf_siren_amd import Embedding, NeRF, render_rays
     g = golden("g15_psnr")
+    nerf_siren_amd.set_math("bf16x3" if impl.endswith("bf16x3") else "fp32")
     S, F, B = int(g["cfg_S"]), int(g["cfg_F"]), int(g["cfg_batch"])
     steps, every = int(g["cfg_steps"]), int(g["cfg_eval_every"])
     ms = []
@@ -636,7 +639,7 @@ def test_psnr_parity(golden, dev, impl):
     emb = [Embedding(3, 10), Embedding(3, 4)]
     rays, tgt = T(g["rays"], dev), T(g["target"], dev)
     val_rays, val_tgt = T(g["val_rays"], dev), T(g["val_target"], dev)
-    if impl == "fused":
+    if impl.startswith("fused"):
         from nerf_siren_amd.training import FusedAdam, FusedMSELoss
         opt = FusedAdam(ms, lr=float(g["cfg_lr"]), eps=1e-8)
         loss_fn = FusedMSELoss(unit_grad=True)
@@ -662,8 +665,9 @@ def test_psnr_parity(golden, dev, impl):
         opt.zero_grad()
         loss.backward()
         opt.step()
+    nerf_siren_amd.set_math("fp32")
     ref = g["psnr"]
-    print("psnr hip", np.round(psnr, 3), "reference", np.round(ref, 3))
+    print(impl, "psnr hip", np.round(psnr, 3), "reference", np.round(ref, 3))
     assert len(psnr) == len(ref)
     assert abs(psnr[0] - ref[0]) < 0.01                     # untrained: identical models
     assert np.abs(np.array(psnr) - ref).max() < 0.1, (psnr, ref)
