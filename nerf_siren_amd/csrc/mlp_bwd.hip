@@ -383,6 +383,166 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
     }
 }
 
+// ---------------------------------------------------------------------------
+// 2b. the 256 x 256 tasks of the dW GEMM on the bf16 matrix cores (opt-in split-bf16 math).
+//     dW = dZ^T . X needs BOTH operands split into their three bf16 terms.  Doing that per wave on the MFMA
+//     fragments would cost ~4 vector instructions per MFMA; here the workgroup splits every value exactly ONCE while
+//     staging it: a thread loads 4 consecutive points of a row (global -> registers, as in the fp32 kernel), splits
+//     them in registers and writes the bf16 terms into an LDS image laid out for v_mfma_f32_32x32x16_bf16 fragments;
+//     the MFMA loop then only reads ready fragments (one ds_read_b128 per term).  One 16-point k-step per barrier,
+//     two LDS buffers of 48 KiB; the staging of k-step i+1 (8 float4 per thread: load, split, three 8-byte LDS writes)
+//     is dealt out over the 16 accumulator units of k-step i, ~2 vector instructions per MFMA, hidden by the XDL pipe.
+//     LDS image of a k-step: [term 3][block 16 (8 dZ + 8 X)][row 32][16 points] bf16, the two 16-byte halves of a row
+//     swapped on rows with bit 2 set (rows r and r+4 would otherwise hit the same banks).
+// ---------------------------------------------------------------------------
+constexpr int DWF_KSTEP_BYTES = 3 * 16 * 1024;
+
+__device__ __forceinline__ void dw_task_bf16x3(const DwTask &T, int chunk, const float *__restrict__ work,
+                                               const float *__restrict__ saved, int64_t ld, float *__restrict__ partial,
+                                               char *lds) {
+    constexpr int JW = 4, KW = 4;                       // blocks per wave; waves 2 x 2 over the 8 x 8 blocks
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
+    const int wj = wid >> 1, wk = wid & 1;
+    const int64_t tiles = ld / 32;
+    const int64_t t_lo = tiles * chunk / T.chunks, t_hi = tiles * (chunk + 1) / T.chunks;
+    const int64_t k_lo = 2 * t_lo, k_hi = 2 * t_hi;     // k-steps of 16 points
+
+    // staging: thread (srow = tid>>2, c = tid&3), slot j = rows 64j + srow of the 512-row (dZ | X) operand,
+    // points 16s + 4c .. +3 of the k-step.  Slots 0..3 are dZ rows, 4..7 X rows.
+    const int srow = tid >> 2, c = tid & 3;
+    const float *abase = work + (int64_t)T.a_row0 * 32, *bbase = saved + (int64_t)T.b_row0 * 32;
+    const unsigned voff = (unsigned)(srow * 32 + 4 * c);
+    f32x4 st[8];
+    auto load_slot = [&](int j, int64_t ks) {
+        const int64_t t = ks >> 1;
+        const int s = (int)(ks & 1);
+        const float *src = (j < 4) ? abase + t * (int64_t)(W_ROWS * 32) + j * 2048 + 16 * s
+                                   : bbase + t * (int64_t)(SAVED_ROWS * 32) + (j - 4) * 2048 + 16 * s;
+        st[j] = ldg4(src + voff);
+    };
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // row sums of dZ (bias gradient): rows 64j + srow, this thread's points
+    // LDS byte offset of this thread's 8 bytes inside (term 0, block 2j + (srow>>5)): row r = srow & 31
+    const int r = srow & 31;
+    const unsigned woff = (unsigned)(((srow >> 5) * 1024) + r * 32 + (((c >> 1) ^ ((r >> 2) & 1)) * 16) + (c & 1) * 8);
+    auto split_write = [&](int j, char *buf, bool real) {      // real = false: the redundant restaging past the end
+        const f32x4 v = st[j];
+        if (j < 4) bsum[j] += real ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+        unsigned w0[3], w1[3];
+        split_pair(v[0], v[1], w0);
+        split_pair(v[2], v[3], w1);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2 *>(buf + (t * 16 + 2 * j) * 1024 + woff) = u32x2{w0[t], w1[t]};
+        }
+    };
+
+    f32x16 acc[JW][KW];
+#pragma unroll
+    for (int a = 0; a < JW; ++a)
+#pragma unroll
+        for (int b = 0; b < KW; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+    char *buf0 = lds, *buf1 = lds + DWF_KSTEP_BYTES;
+    if (k_lo < k_hi) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) load_slot(j, k_lo);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split_write(j, buf0, true);
+        if (k_lo + 1 < k_hi) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) load_slot(j, k_lo + 1);
+        }
+    }
+    __syncthreads();
+    // fragment byte offset of this lane inside a (term, block) image
+    const unsigned foff = (unsigned)((lane & 31) * 32 + ((half ^ (((lane & 31) >> 2) & 1)) * 16));
+    auto kstep = [&](int64_t ks, const char *cur, char *nxt) __attribute__((always_inline)) {
+        const int64_t k2 = (ks + 2 < k_hi) ? ks + 2 : k_hi - 1;     // past the end: restage the last one (branch-free)
+        u32x4 a[JW][3], b[2][3];
+#pragma unroll
+        for (int x = 0; x < JW; ++x)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[x][t] = *reinterpret_cast<const u32x4 *>(cur + (t * 16 + wj * JW + x) * 1024 + foff);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) b[0][t] = *reinterpret_cast<const u32x4 *>(cur + (t * 16 + 8 + wk * KW) * 1024 + foff);
+#pragma unroll
+        for (int y = 0; y < KW; ++y) {
+            if (y + 1 < KW) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    b[(y + 1) & 1][t] = *reinterpret_cast<const u32x4 *>(cur + (t * 16 + 8 + wk * KW + y + 1) * 1024 + foff);
+            }
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[y & 1][0]), b2 = __builtin_bit_cast(bf16x8, b[y & 1][1]),
+                         b3 = __builtin_bit_cast(bf16x8, b[y & 1][2]);
+#pragma unroll
+            for (int x = 0; x < JW; ++x) {
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, a[x][0]), a2 = __builtin_bit_cast(bf16x8, a[x][1]),
+                             a3 = __builtin_bit_cast(bf16x8, a[x][2]);
+                f32x16 cc = acc[x][y];
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, cc, 0, 0, 0);      // small terms first
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, cc, 0, 0, 0);
+                acc[x][y] = cc;
+                const int u = y * JW + x;                            // unit 0..15: staging slot u/2 on even units
+                if ((u & 1) == 0) {
+                    split_write(u >> 1, nxt, ks + 1 < k_hi);
+                    load_slot(u >> 1, k2);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    for (int64_t ks = k_lo; ks < k_hi; ks += 2) {
+        kstep(ks, buf0, buf1);
+        if (ks + 1 < k_hi) kstep(ks + 1, buf1, buf0);
+    }
+    // partial slab [chunk][256][256] then bias slab [chunk][256] (same layout as dw_task<., ., ., .>)
+    float *slab = partial + T.part_off + (int64_t)chunk * (256 * 257);
+#pragma unroll
+    for (int x = 0; x < JW; ++x)
+#pragma unroll
+        for (int y = 0; y < KW; ++y)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int j = 32 * (wj * JW + x) + 8 * (q >> 2) + 4 * half + (q & 3);
+                const int k = 32 * (wk * KW + y) + (lane & 31);
+                slab[j * 256 + k] = acc[x][y][q];
+            }
+    // bias: the four threads c = 0..3 of a row are neighbours in the wave
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float sum = bsum[j];
+        sum += __shfl_xor(sum, 1, WAVE);
+        sum += __shfl_xor(sum, 2, WAVE);
+        if (c == 0) slab[256 * 256 + 64 * j + srow] = sum;
+    }
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+nerf_dw_bf16x3_kernel(DwPlan plan, const float *__restrict__ work, const float *__restrict__ saved, int64_t ld,
+                      float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int ti = 0;
+    for (int i = 1; i < plan.n_tasks; ++i)
+        if ((int)blockIdx.x >= plan.t[i].wg0) ti = i;
+    const DwTask T = plan.t[ti];
+    const int chunk = blockIdx.x - T.wg0;
+    switch (T.kind) {
+        case 0: dw_task_bf16x3(T, chunk, work, saved, ld, partial, reinterpret_cast<char *>(lds)); break;
+        case 1: dw_task<2, 2, 4, 1>(T, chunk, work, saved, ld, partial, lds); break;
+        case 2: dw_task<1, 8, 4, 1>(T, chunk, work, saved, ld, partial, lds); break;
+        case 3: dw_task<1, 1, 4, 1>(T, chunk, work, saved, ld, partial, lds); break;
+        case 4: dw_task<1, 1, 1, 4>(T, chunk, work, saved, ld, partial, lds); break;
+        default: dw_task<1, 2, 1, 4>(T, chunk, work, saved, ld, partial, lds); break;
+    }
+}
+
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 nerf_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__restrict__ saved, int64_t ld,
                float *__restrict__ partial) {
@@ -439,7 +599,7 @@ __global__ void nerf_dw_reduce_kernel(DwPlan plan, const float *__restrict__ par
 static const int KIND_JB[6] = {8, 8, 4, 4, 1, 1};
 static const int KIND_KB[6] = {8, 2, 8, 1, 4, 8};
 
-static DwPlan make_plan(int64_t ld) {
+static DwPlan make_plan(int64_t ld, bool fast = false) {
     DwPlan P;
     int n = 0;
     auto add = [&](int kind, int a_row0, int a_valid, int b_row0, int b_valid, int param, int col0, int in_f, int bias) {
@@ -464,7 +624,11 @@ static DwPlan make_plan(int64_t ld) {
     // the critical path when sized by MFMA work alone)
     // 8 x 26 + 2 x 9 + 14 + 5 + 5 + 6 = 256 workgroups: every CU gets exactly one (the LDS tiles of a workgroup
     // fill a CU), so the kernel takes one workgroup's time; leaving CUs without a chunk costs their share outright
-    static const int base[6] = {26, 9, 14, 5, 5, 6};
+    static const int base_fp32[6] = {26, 9, 14, 5, 5, 6};
+    // split-bf16 variant: the 256 x 256 tasks run ~2x faster per tile, so the fp32 tasks get the larger share of CUs:
+    // 8 x 20 + 2 x 17 + 28 + 11 + 11 + 12 = 256
+    static const int base_fast[6] = {20, 17, 28, 11, 11, 12};
+    const int *base = fast ? base_fast : base_fp32;
     const int64_t tiles = ld / 32;
     int wg = 0, off = 0;
     for (int i = 0; i < n; ++i) {
@@ -494,8 +658,8 @@ extern "C" {
 
 size_t nerfmi_nerf_backward_workspace_floats(int64_t n_points) {
     const int64_t ld = pad_points(n_points < 1 ? 1 : n_points);
-    const DwPlan P = make_plan(ld);
-    return (size_t)W_ROWS * (size_t)(ld + 32) + plan_partial_floats(P);   // + the dump tile (mlp_core.h RowImage)
+    const size_t pa = plan_partial_floats(make_plan(ld, false)), pb = plan_partial_floats(make_plan(ld, true));
+    return (size_t)W_ROWS * (size_t)(ld + 32) + (pa > pb ? pa : pb);   // + the dump tile (mlp_core.h RowImage)
 }
 
 static int backward_impl(const char *who, const float *packed, const void *fast, int n_rays, int n_per_ray,
@@ -514,12 +678,15 @@ static int backward_impl(const char *who, const float *packed, const void *fast,
     float *work = workspace;
     float *partial = workspace + (size_t)W_ROWS * (ld + 32);
     const int64_t waves = (n_points + 31) / 32;
-    const DwPlan P = make_plan(ld);
+    const DwPlan P = make_plan(ld, fast != nullptr);
     const size_t lds = sizeof(float) * 2 * 512 * LROW;  // two 73 728-B tile buffers (> the 64 KiB default dynamic-LDS limit)
+    static_assert(2 * DWF_KSTEP_BYTES <= sizeof(float) * 2 * 512 * LROW, "the split-bf16 k-step buffers fit in the same allocation");
     static thread_local bool lds_attr_set = false;
     if (!lds_attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_dw_bf16x3_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_backward_chain_bf16x3_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess) {
             (void)hipGetLastError();
@@ -534,7 +701,10 @@ static int backward_impl(const char *who, const float *packed, const void *fast,
     else
         hipLaunchKernelGGL(nerf_backward_chain_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
                            grad_out, n_points, ld, work);
-    hipLaunchKernelGGL(nerf_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
+    if (fast)
+        hipLaunchKernelGGL(nerf_dw_bf16x3_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
+    else
+        hipLaunchKernelGGL(nerf_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
     hipLaunchKernelGGL(nerf_dw_reduce_kernel, dim3(128, P.n_tasks), dim3(256), 0, st, P, partial, G);
     return check_launch(who);
 }
