@@ -395,45 +395,53 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
 //     LDS image of a k-step: [term 3][block 16 (8 dZ + 8 X)][row 32][16 points] bf16, the two 16-byte halves of a row
 //     swapped on rows with bit 2 set (rows r and r+4 would otherwise hit the same banks).
 // ---------------------------------------------------------------------------
-constexpr int DWF_KSTEP_BYTES = 3 * 16 * 1024;
+constexpr int DWF_KSTEP_BYTES = 3 * 16 * 1024;      // largest task: 8 + 8 blocks
 
+// JB x KB blocks per workgroup, JW x KW per wave, waves WJ x WK (JB = JW*WJ, KB = KW*WK, JB even, JB + KB even)
+template <int JB, int KB, int JW, int KW, int WK>
 __device__ __forceinline__ void dw_task_bf16x3(const DwTask &T, int chunk, const float *__restrict__ work,
                                                const float *__restrict__ saved, int64_t ld, float *__restrict__ partial,
                                                char *lds) {
-    constexpr int JW = 4, KW = 4;                       // blocks per wave; waves 2 x 2 over the 8 x 8 blocks
+    constexpr int NB = JB + KB;                         // blocks of the (dZ | X) operand
+    constexpr int NS = NB / 2;                          // staging slots per thread (64 rows each); the first JB/2 are dZ
+    constexpr int NU = JW * KW;                         // accumulator units per wave
+    constexpr int KBYTES = 3 * NB * 1024;               // one k-step image
+    static_assert(JB % 2 == 0 && NB % 2 == 0 && 2 * KBYTES <= 2 * DWF_KSTEP_BYTES, "task shape");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
-    const int wj = wid >> 1, wk = wid & 1;
+    const int wj = wid / WK, wk = wid % WK;
     const int64_t tiles = ld / 32;
     const int64_t t_lo = tiles * chunk / T.chunks, t_hi = tiles * (chunk + 1) / T.chunks;
     const int64_t k_lo = 2 * t_lo, k_hi = 2 * t_hi;     // k-steps of 16 points
 
-    // staging: thread (srow = tid>>2, c = tid&3), slot j = rows 64j + srow of the 512-row (dZ | X) operand,
-    // points 16s + 4c .. +3 of the k-step.  Slots 0..3 are dZ rows, 4..7 X rows.
+    // staging: thread (srow = tid>>2, c = tid&3), slot j = rows 64j + srow of the (dZ | X) operand,
+    // points 16s + 4c .. +3 of the k-step
     const int srow = tid >> 2, c = tid & 3;
     const float *abase = work + (int64_t)T.a_row0 * 32, *bbase = saved + (int64_t)T.b_row0 * 32;
     const unsigned voff = (unsigned)(srow * 32 + 4 * c);
-    f32x4 st[8];
+    f32x4 st[NS];
     auto load_slot = [&](int j, int64_t ks) {
         const int64_t t = ks >> 1;
         const int s = (int)(ks & 1);
-        const float *src = (j < 4) ? abase + t * (int64_t)(W_ROWS * 32) + j * 2048 + 16 * s
-                                   : bbase + t * (int64_t)(SAVED_ROWS * 32) + (j - 4) * 2048 + 16 * s;
+        const float *src = (j < JB / 2) ? abase + t * (int64_t)(W_ROWS * 32) + j * 2048 + 16 * s
+                                        : bbase + t * (int64_t)(SAVED_ROWS * 32) + (j - JB / 2) * 2048 + 16 * s;
         st[j] = ldg4(src + voff);
     };
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // row sums of dZ (bias gradient): rows 64j + srow, this thread's points
+    float bsum[JB / 2];                                 // row sums of dZ (bias gradient): rows 64j + srow, this thread's points
+#pragma unroll
+    for (int j = 0; j < JB / 2; ++j) bsum[j] = 0.f;
     // LDS byte offset of this thread's 8 bytes inside (term 0, block 2j + (srow>>5)): row r = srow & 31
     const int r = srow & 31;
     const unsigned woff = (unsigned)(((srow >> 5) * 1024) + r * 32 + (((c >> 1) ^ ((r >> 2) & 1)) * 16) + (c & 1) * 8);
     auto split_write = [&](int j, char *buf, bool real) {      // real = false: the redundant restaging past the end
         const f32x4 v = st[j];
-        if (j < 4) bsum[j] += real ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+        if (j < JB / 2) bsum[j] += real ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
         unsigned w0[3], w1[3];
         split_pair(v[0], v[1], w0);
         split_pair(v[2], v[3], w1);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<u32x2 *>(buf + (t * 16 + 2 * j) * 1024 + woff) = u32x2{w0[t], w1[t]};
+            *reinterpret_cast<u32x2 *>(buf + (t * NB + 2 * j) * 1024 + woff) = u32x2{w0[t], w1[t]};
         }
     };
 
@@ -445,15 +453,15 @@ __device__ __forceinline__ void dw_task_bf16x3(const DwTask &T, int chunk, const
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
-    char *buf0 = lds, *buf1 = lds + DWF_KSTEP_BYTES;
+    char *buf0 = lds, *buf1 = lds + KBYTES;
     if (k_lo < k_hi) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) load_slot(j, k_lo);
+        for (int j = 0; j < NS; ++j) load_slot(j, k_lo);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) split_write(j, buf0, true);
+        for (int j = 0; j < NS; ++j) split_write(j, buf0, true);
         if (k_lo + 1 < k_hi) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) load_slot(j, k_lo + 1);
+            for (int j = 0; j < NS; ++j) load_slot(j, k_lo + 1);
         }
     }
     __syncthreads();
@@ -465,15 +473,15 @@ __device__ __forceinline__ void dw_task_bf16x3(const DwTask &T, int chunk, const
 #pragma unroll
         for (int x = 0; x < JW; ++x)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) a[x][t] = *reinterpret_cast<const u32x4 *>(cur + (t * 16 + wj * JW + x) * 1024 + foff);
+            for (int t = 0; t < 3; ++t) a[x][t] = *reinterpret_cast<const u32x4 *>(cur + (t * NB + wj * JW + x) * 1024 + foff);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) b[0][t] = *reinterpret_cast<const u32x4 *>(cur + (t * 16 + 8 + wk * KW) * 1024 + foff);
+        for (int t = 0; t < 3; ++t) b[0][t] = *reinterpret_cast<const u32x4 *>(cur + (t * NB + JB + wk * KW) * 1024 + foff);
 #pragma unroll
         for (int y = 0; y < KW; ++y) {
             if (y + 1 < KW) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
-                    b[(y + 1) & 1][t] = *reinterpret_cast<const u32x4 *>(cur + (t * 16 + 8 + wk * KW + y + 1) * 1024 + foff);
+                    b[(y + 1) & 1][t] = *reinterpret_cast<const u32x4 *>(cur + (t * NB + JB + wk * KW + y + 1) * 1024 + foff);
             }
             const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[y & 1][0]), b2 = __builtin_bit_cast(bf16x8, b[y & 1][1]),
                          b3 = __builtin_bit_cast(bf16x8, b[y & 1][2]);
@@ -489,11 +497,13 @@ __device__ __forceinline__ void dw_task_bf16x3(const DwTask &T, int chunk, const
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, cc, 0, 0, 0);
                 acc[x][y] = cc;
-                const int u = y * JW + x;                            // unit 0..15: staging slot u/2 on even units
-                if ((u & 1) == 0) {
-                    split_write(u >> 1, nxt, ks + 1 < k_hi);
-                    load_slot(u >> 1, k2);
-                }
+                const int u = y * JW + x;                            // the staging slots are dealt out over the units
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+                    if ((i * NU) / NS == u) {
+                        split_write(i, nxt, ks + 1 < k_hi);
+                        load_slot(i, k2);
+                    }
             }
         }
         __syncthreads();
@@ -502,8 +512,8 @@ __device__ __forceinline__ void dw_task_bf16x3(const DwTask &T, int chunk, const
         kstep(ks, buf0, buf1);
         if (ks + 1 < k_hi) kstep(ks + 1, buf1, buf0);
     }
-    // partial slab [chunk][256][256] then bias slab [chunk][256] (same layout as dw_task<., ., ., .>)
-    float *slab = partial + T.part_off + (int64_t)chunk * (256 * 257);
+    // partial slab [chunk][32 JB][32 KB] then bias slab [chunk][32 JB] (same layout as dw_task<., ., ., .>)
+    float *slab = partial + T.part_off + (int64_t)chunk * (JB * 32 * (KB * 32 + 1));
 #pragma unroll
     for (int x = 0; x < JW; ++x)
 #pragma unroll
@@ -512,35 +522,45 @@ __device__ __forceinline__ void dw_task_bf16x3(const DwTask &T, int chunk, const
             for (int q = 0; q < 16; ++q) {
                 const int j = 32 * (wj * JW + x) + 8 * (q >> 2) + 4 * half + (q & 3);
                 const int k = 32 * (wk * KW + y) + (lane & 31);
-                slab[j * 256 + k] = acc[x][y][q];
+                slab[j * (KB * 32) + k] = acc[x][y][q];
             }
     // bias: the four threads c = 0..3 of a row are neighbours in the wave
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < JB / 2; ++j) {
         float sum = bsum[j];
         sum += __shfl_xor(sum, 1, WAVE);
         sum += __shfl_xor(sum, 2, WAVE);
-        if (c == 0) slab[256 * 256 + 64 * j + srow] = sum;
+        if (c == 0) slab[JB * 32 * KB * 32 + 64 * j + srow] = sum;
     }
 }
+
+#ifdef NERFMI_TIMING
+__device__ unsigned long long nerfmi_dbg_dw[512];        // per-workgroup shader-clock duration (experiment builds)
+#endif
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 nerf_dw_bf16x3_kernel(DwPlan plan, const float *__restrict__ work, const float *__restrict__ saved, int64_t ld,
                       float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef NERFMI_TIMING
+    const unsigned long long t_start = __builtin_readcyclecounter();
+#endif
     int ti = 0;
     for (int i = 1; i < plan.n_tasks; ++i)
         if ((int)blockIdx.x >= plan.t[i].wg0) ti = i;
     const DwTask T = plan.t[ti];
     const int chunk = blockIdx.x - T.wg0;
     switch (T.kind) {
-        case 0: dw_task_bf16x3(T, chunk, work, saved, ld, partial, reinterpret_cast<char *>(lds)); break;
-        case 1: dw_task<2, 2, 4, 1>(T, chunk, work, saved, ld, partial, lds); break;
-        case 2: dw_task<1, 8, 4, 1>(T, chunk, work, saved, ld, partial, lds); break;
+        case 0: dw_task_bf16x3<8, 8, 4, 4, 2>(T, chunk, work, saved, ld, partial, reinterpret_cast<char *>(lds)); break;
+        case 1: dw_task_bf16x3<8, 2, 2, 2, 1>(T, chunk, work, saved, ld, partial, reinterpret_cast<char *>(lds)); break;
+        case 2: dw_task_bf16x3<4, 8, 2, 4, 2>(T, chunk, work, saved, ld, partial, reinterpret_cast<char *>(lds)); break;
         case 3: dw_task<1, 1, 4, 1>(T, chunk, work, saved, ld, partial, lds); break;
         case 4: dw_task<1, 1, 1, 4>(T, chunk, work, saved, ld, partial, lds); break;
         default: dw_task<1, 2, 1, 4>(T, chunk, work, saved, ld, partial, lds); break;
     }
+#ifdef NERFMI_TIMING
+    if (threadIdx.x == 0) nerfmi_dbg_dw[blockIdx.x] = __builtin_readcyclecounter() - t_start;
+#endif
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -626,8 +646,9 @@ static DwPlan make_plan(int64_t ld, bool fast = false) {
     // fill a CU), so the kernel takes one workgroup's time; leaving CUs without a chunk costs their share outright
     static const int base_fp32[6] = {26, 9, 14, 5, 5, 6};
     // split-bf16 variant: the 256 x 256 tasks run ~2x faster per tile, so the fp32 tasks get the larger share of CUs:
-    // 8 x 20 + 2 x 17 + 28 + 11 + 11 + 12 = 256
-    static const int base_fast[6] = {20, 17, 28, 11, 11, 12};
+    // 8 x 24 + 2 x 12 + 18 + 6 + 6 + 10 = 256, from measured per-task workgroup times (tools/exp_dw_timing.py:
+    // 38.2 / 18.5 / 25.5 / 8.4 / 8.5 / 12.6 M cycles per task at 4096 tiles); the tiny tasks 3..5 stay on the fp32 path
+    static const int base_fast[6] = {24, 12, 18, 6, 6, 10};
     const int *base = fast ? base_fast : base_fp32;
     const int64_t tiles = ld / 32;
     int wg = 0, off = 0;
@@ -661,6 +682,12 @@ size_t nerfmi_nerf_backward_workspace_floats(int64_t n_points) {
     const size_t pa = plan_partial_floats(make_plan(ld, false)), pb = plan_partial_floats(make_plan(ld, true));
     return (size_t)W_ROWS * (size_t)(ld + 32) + (pa > pb ? pa : pb);   // + the dump tile (mlp_core.h RowImage)
 }
+
+#ifdef NERFMI_TIMING
+extern "C" int nerfmi_debug_timing_dw(unsigned long long *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(nerfmi_dbg_dw), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : 1;
+}
+#endif
 
 static int backward_impl(const char *who, const float *packed, const void *fast, int n_rays, int n_per_ray,
                          const float *saved, const float *grad_out, float *const *grad_params, float *workspace,
