@@ -567,6 +567,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 nerf_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__restrict__ saved, int64_t ld,
                float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef NERFMI_TIMING
+    const unsigned long long t_start = __builtin_readcyclecounter();
+#endif
     int ti = 0;
     for (int i = 1; i < plan.n_tasks; ++i)
         if ((int)blockIdx.x >= plan.t[i].wg0) ti = i;
@@ -580,6 +583,9 @@ nerf_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__restr
         case 4: dw_task<1, 1, 1, 4>(T, chunk, work, saved, ld, partial, lds); break;
         default: dw_task<1, 2, 1, 4>(T, chunk, work, saved, ld, partial, lds); break;
     }
+#ifdef NERFMI_TIMING
+    if (threadIdx.x == 0) nerfmi_dbg_dw[blockIdx.x] = __builtin_readcyclecounter() - t_start;
+#endif
 }
 
 struct GradPtrs {

@@ -30,11 +30,20 @@ gout = torch.randn(npts, 4, device=dev)
 from nerf_siren_amd import ops
 grads = ops.flat_views(torch.empty(ops.PARAM_NUMEL, device=dev))
 arr = (C.c_void_p * 24)(*[g.data_ptr() for g in grads])
-fn = lib.nerfmi_nerf_backward_rays_fast
-fn.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_void_p), vp, vp]
+FP32 = len(sys.argv) > 3 and sys.argv[3] == "fp32"
+if FP32:
+    fn = lib.nerfmi_nerf_backward_rays
+    fn.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_void_p), vp, vp]
+    rays = torch.randn(N_RAYS, 8, device=dev)
+    z = torch.rand(N_RAYS, P, device=dev)
+    call = lambda: fn(packed.data_ptr(), rays.data_ptr(), z.data_ptr(), N_RAYS, P, saved.data_ptr(), gout.data_ptr(), arr, ws.data_ptr(), None)
+else:
+    fn = lib.nerfmi_nerf_backward_rays_fast
+    fn.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_void_p), vp, vp]
+    call = lambda: fn(packed.data_ptr(), fast.data_ptr(), N_RAYS, P, saved.data_ptr(), gout.data_ptr(), arr, ws.data_ptr(), None)
 fn.restype = C.c_int
 for _ in range(5):
-    assert fn(packed.data_ptr(), fast.data_ptr(), N_RAYS, P, saved.data_ptr(), gout.data_ptr(), arr, ws.data_ptr(), None) == 0
+    assert call() == 0
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 512)()
 assert lib.nerfmi_debug_timing_dw(buf) == 0
