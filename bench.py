@@ -48,6 +48,7 @@ def parse():
                     help="training: nerf_siren_amd.training.FusedAdam + FusedMSELoss (one launch each) or torch.optim.Adam "
                          "+ elementwise loss -- same arithmetic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-opt-in", action="store_true", help="skip the extra timed loop on the opt-in split-bf16 math")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work in the bounded cpu_baseline sample")
     return ap.parse_args()
 
@@ -237,6 +238,27 @@ def main():
     dt = float(tmax.item())
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+
+    # The same K steps once more on the OPT-IN split-bf16 math (fp32-level accuracy on the bf16 matrix cores, same parity
+    # tests) -- reported beside the headline, never as `value`.
+    opt_in = None
+    if args.math == "fp32" and not siren and not args.no_opt_in:
+        import nerf_siren_amd
+        nerf_siren_amd.set_math("bf16x3")
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        barrier()
+        dt2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dt2, op=dist.ReduceOp.MAX)
+        nerf_siren_amd.set_math("fp32")
+        dt2 = float(dt2.item())
+        opt_in = {"math": "bf16x3 (exact 3-way bf16 split of both operands, 6 bf16 MFMA per product, fp32 accumulate)",
+                  "value": world * B * 192 * args.steps / dt2, "unit": "ray-samples/s", "ms_per_step": dt2 / args.steps * 1e3}
     # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc summary (tools/pmc_summary.py);
     # counters cannot be collected from inside the timed run
     traffic = None
@@ -275,6 +297,8 @@ def main():
                          "frac": achieved / peak, "traffic": traffic,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": kern_ms},
         }
+        if opt_in is not None:
+            out["opt_in"] = opt_in
         if world == 1 and not args.no_cpu_baseline and not siren:
             out["cpu_baseline"] = cpu_baseline(args.mode, budget_s=args.cpu_seconds)
         print(json.dumps(out), flush=True)
