@@ -115,8 +115,8 @@ def main():
 
     B = args.batch
     if args.math != "fp32":
-        if args.field != "nerf":
-            raise SystemExit("--math bf16x3 applies to --field nerf")
+        if args.field == "siren" and args.mode != "infer":
+            raise SystemExit("--field siren supports --mode infer only")
         import nerf_siren_amd
         nerf_siren_amd.set_math(args.math)
     models = []
@@ -196,6 +196,19 @@ def main():
             return out
 
         ops.siren_forward_rays = timed_siren
+        orig_siren_fast = ops.siren_forward_rays_fast
+
+        def timed_siren_fast(packed, fast, rays, z, freq, phase, rpc, sigma_only=False):
+            if z.shape[1] != 128:
+                return orig_siren_fast(packed, fast, rays, z, freq, phase, rpc, sigma_only)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = orig_siren_fast(packed, fast, rays, z, freq, phase, rpc, sigma_only)
+            b.record()
+            ev.append((a, b))
+            return out
+
+        ops.siren_forward_rays_fast = timed_siren_fast
 
     def step(i):
         rays = rays_pool[i % n_pool]

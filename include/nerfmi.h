@@ -120,6 +120,14 @@ int nerfmi_siren_forward_rays(const float *packed, const float *rays, const floa
                               const float *phase_shifts, int n_rays, int n_per_ray, int64_t rays_per_cond,
                               int sigma_only, float *out, nerfmi_stream_t stream);
 
+/* OPT-IN split-bf16 math for the FiLM-SIREN field (see nerfmi_nerf_forward_rays_fast): `fast`
+ * (nerfmi_siren_fast_bytes() bytes) is derived from the SIREN `packed` blob by nerfmi_siren_pack_fast. */
+size_t nerfmi_siren_fast_bytes(void);
+int nerfmi_siren_pack_fast(const float *packed, void *fast, nerfmi_stream_t stream);
+int nerfmi_siren_forward_rays_fast(const float *packed, const void *fast, const float *rays, const float *z,
+                                   const float *frequencies, const float *phase_shifts, int n_rays, int n_per_ray,
+                                   int64_t rays_per_cond, int sigma_only, float *out, nerfmi_stream_t stream);
+
 /* ---- a8: compositing -- models/rendering.py:162-190 ----------------------
  * field: (n_rays,n_per_ray,4) [rgb,sigma] or, when sigma_only, (n_rays,n_per_ray)
  * sigma (the weights_only branch :179-180: only weights/opacity are produced).

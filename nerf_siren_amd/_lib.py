@@ -32,6 +32,9 @@ SIGNATURES = {
     "nerfmi_nerf_backward_workspace_floats": (C.c_size_t, [_i64]),
     "nerfmi_nerf_backward_rays": (_i, [_f, _f, _f, _i, _i, _f, _f, C.POINTER(C.c_void_p), _f, _f]),
     "nerfmi_siren_packed_floats": (C.c_size_t, []),
+    "nerfmi_siren_fast_bytes": (C.c_size_t, []),
+    "nerfmi_siren_pack_fast": (_i, [_f, _f, _f]),
+    "nerfmi_siren_forward_rays_fast": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i64, _i, _f, _f]),
     "nerfmi_siren_pack": (_i, [C.POINTER(C.c_void_p), _f, _f]),
     "nerfmi_siren_forward_points": (_i, [_f, _f, _f, _f, _f, _i64, _i64, _i, _f, _f]),
     "nerfmi_siren_forward_rays": (_i, [_f, _f, _f, _f, _f, _i, _i, _i64, _i, _f, _f]),

@@ -71,7 +71,9 @@ struct NoHook {
 
 //  * the accumulators start from bias * bias_scale (bias_scale = 1: plain bias; the backward chain starts d h8 from
 //    w_sigma * d sigma this way); bias == nullptr starts from zero.
-template <int KB0, int KB1, int JB, bool RELU1, bool FIRST, class Pre0 = NoHook, class Pre1 = NoHook>
+//  * PH: ring phase of the layer's stage 0 (slot = (stage + PH) % 4); 0 when every earlier layer of the kernel is a
+//    multiple of four stages.
+template <int KB0, int KB1, int JB, bool RELU1, bool FIRST, class Pre0 = NoHook, class Pre1 = NoHook, int PH = 0>
 __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, const float *__restrict__ bias,
                                              const f32x16 *in0, const f32x16 *in1, f32x16 *acc, char *wlds,
                                              FastStage &fs, int wid, int lane, Pre0 pre0 = Pre0(), Pre1 pre1 = Pre1(),
@@ -87,10 +89,10 @@ __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, c
         fs.st[i] = *reinterpret_cast<const f32x4 *>(gsrc + (int64_t)(stage * PIECES + i) * 1024);
     };
     auto lwrite = [&](int stage, int i) {
-        *reinterpret_cast<f32x4 *>(ldst + ((stage % FSLOT) * PIECES + i) * 1024) = fs.st[i];
+        *reinterpret_cast<f32x4 *>(ldst + (((stage + PH) % FSLOT) * PIECES + i) * 1024) = fs.st[i];
     };
     auto lread = [&](int uu, int t) {
-        return *reinterpret_cast<const u32x4 *>(lsrc + (((uu / US) % FSLOT) * PIECES + (uu % US) * 3 + t) * 1024);
+        return *reinterpret_cast<const u32x4 *>(lsrc + (((uu / US + PH) % FSLOT) * PIECES + (uu % US) * 3 + t) * 1024);
     };
     if (FIRST) {
         __syncthreads();
@@ -180,6 +182,49 @@ __device__ __forceinline__ void layer_bf16x3(const __bf16 *__restrict__ wbase, c
 #pragma unroll
                     for (int d = 0; d < 4; ++d) cur[a][b][d] = nxt[a][b][d];
         }
+    }
+}
+
+// x = p0 + p1 + p2 exactly (each step round-to-nearest-even)
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&sp)[3]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        const float r1 = x[j] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        sp[0][j] = h; sp[1][j] = m; sp[2][j] = (__bf16)r2;
+    }
+}
+
+// fast image: per layer, unit U = (kb*2 + s)*JB + jb (input-block-major: a layer walks its INPUT blocks in the
+// outer loop, so each input block is split just before use and all JB accumulators advance together);
+// unit -> 3 x 1 KiB: split i at bytes (unit0 + U)*3072 + i*1024 + lane*16 (8 bf16).  Built from the fp32
+// fragment image: the lane's floats of groups 2s and 2s+1 of (jb,kb) ARE its 8 k-slots of k-step s.
+struct FastLayer { int off, JB, KB, unit0; };   // float offset in `packed`, output blocks, input blocks, first fast unit
+constexpr int MAX_FAST_LAYERS = 20;
+struct FastTable {
+    FastLayer l[MAX_FAST_LAYERS];
+    int n, n_units;
+};
+
+static __global__ void pack_bf16x3_table_kernel(FastTable T, const float *__restrict__ packed, __bf16 *__restrict__ fast) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < T.n_units * 64; idx += gridDim.x * blockDim.x) {
+        const int U = idx >> 6, lane = idx & 63;             // fast unit index; its layer, then its source unit (jb,kb,s)
+        int li = 0;
+        for (int l = 1; l < T.n; ++l)
+            if (U >= T.l[l].unit0) li = l;
+        const FastLayer L = T.l[li];
+        const int rel = U - L.unit0;                         // destination order: (kb*2 + s)*JB + jb
+        const int jb = rel % L.JB, s = (rel / L.JB) & 1, kb = rel / (2 * L.JB);
+        const float *src = packed + L.off + (int64_t)((jb * L.KB + kb) * 2 + s) * 512;
+        const f32x4 v0 = ldg4(src + lane * 4), v1 = ldg4(src + 256 + lane * 4);
+        const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        bf16x8 sp[3];
+        split8(x, sp);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            *reinterpret_cast<bf16x8 *>(fast + ((int64_t)U * 3 + i) * 512 + lane * 8) = sp[i];
     }
 }
 

@@ -15,54 +15,20 @@
 namespace nerfmi {
 
 
-// x = p0 + p1 + p2 exactly (each step round-to-nearest-even)
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&sp)[3]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)x[j];
-        const float r1 = x[j] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        sp[0][j] = h; sp[1][j] = m; sp[2][j] = (__bf16)r2;
-    }
-}
-// fast image: per layer, unit U = (kb*2 + s)*JB + jb (input-block-major: a layer walks its INPUT blocks in the
-// outer loop, so each input block is split just before use and all JB accumulators advance together);
-// unit -> 3 x 1 KiB: split i at bytes (unit_base + U)*3072 + i*1024 + lane*16 (8 bf16).  Built from the fp32
-// fragment image: the lane's floats of groups 2s and 2s+1 of (jb,kb) ARE its 8 k-slots of k-step s.
-struct FastLayer { int off, JB, KB, unit0; };   // float offset in `packed`, output blocks, input blocks, first fast unit
-constexpr int N_FAST_LAYERS = NL_FWD + 9;
-__constant__ FastLayer d_fast_layers[N_FAST_LAYERS] = {
-    {OFF_L1, 8, 2, OFF_L1 / 512}, {OFF_L2, 8, 8, OFF_L2 / 512}, {OFF_L3, 8, 8, OFF_L3 / 512}, {OFF_L4, 8, 8, OFF_L4 / 512},
-    {OFF_L5, 8, 10, OFF_L5 / 512}, {OFF_L6, 8, 8, OFF_L6 / 512}, {OFF_L7, 8, 8, OFF_L7 / 512}, {OFF_L8, 8, 8, OFF_L8 / 512},
-    {OFF_FINAL, 8, 8, OFF_FINAL / 512}, {OFF_DIR, 4, 9, OFF_DIR / 512},
+static FastTable nerf_fast_table() {
+    FastTable T;
+    int n = 0;
+    auto add = [&](int off, int JB, int KB, int unit0) { T.l[n++] = FastLayer{off, JB, KB, unit0}; };
+    const int fwd[NL_FWD][3] = {{OFF_L1, 8, 2}, {OFF_L2, 8, 8}, {OFF_L3, 8, 8}, {OFF_L4, 8, 8}, {OFF_L5, 8, 10},
+                                {OFF_L6, 8, 8}, {OFF_L7, 8, 8}, {OFF_L8, 8, 8}, {OFF_FINAL, 8, 8}, {OFF_DIR, 4, 9}};
+    for (auto &f : fwd) add(f[0], f[1], f[2], f[0] / 512);
     // transposed images of the backward chain, in the order it walks them: (output blocks of dX, contraction blocks)
-    {OFF_TDIR, 8, 4, FAST_FWD_UNITS + (OFF_TDIR - OFF_TRANS) / 512}, {OFF_TFINAL, 8, 8, FAST_FWD_UNITS + (OFF_TFINAL - OFF_TRANS) / 512},
-    {OFF_T8, 8, 8, FAST_FWD_UNITS + (OFF_T8 - OFF_TRANS) / 512}, {OFF_T7, 8, 8, FAST_FWD_UNITS + (OFF_T7 - OFF_TRANS) / 512},
-    {OFF_T6, 8, 8, FAST_FWD_UNITS + (OFF_T6 - OFF_TRANS) / 512}, {OFF_T5, 8, 8, FAST_FWD_UNITS + (OFF_T5 - OFF_TRANS) / 512},
-    {OFF_T4, 8, 8, FAST_FWD_UNITS + (OFF_T4 - OFF_TRANS) / 512}, {OFF_T3, 8, 8, FAST_FWD_UNITS + (OFF_T3 - OFF_TRANS) / 512},
-    {OFF_T2, 8, 8, FAST_FWD_UNITS + (OFF_T2 - OFF_TRANS) / 512}};
-
-__global__ void pack_bf16x3_kernel(const float *__restrict__ packed, __bf16 *__restrict__ fast) {
-    const int n_units = FAST_FWD_UNITS + FAST_T_UNITS;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_units * 64; idx += gridDim.x * blockDim.x) {
-        const int U = idx >> 6, lane = idx & 63;             // fast unit index; its layer, then its source unit (jb,kb,s)
-        int li = 0;
-#pragma unroll
-        for (int l = 1; l < N_FAST_LAYERS; ++l)
-            if (U >= d_fast_layers[l].unit0) li = l;
-        const FastLayer L = d_fast_layers[li];
-        const int rel = U - L.unit0;                         // destination order: (kb*2 + s)*JB + jb
-        const int jb = rel % L.JB, s = (rel / L.JB) & 1, kb = rel / (2 * L.JB);
-        const float *src = packed + L.off + (int64_t)((jb * L.KB + kb) * 2 + s) * 512;
-        const f32x4 v0 = ldg4(src + lane * 4), v1 = ldg4(src + 256 + lane * 4);
-        const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        bf16x8 sp[3];
-        split8(x, sp);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            *reinterpret_cast<bf16x8 *>(fast + ((int64_t)U * 3 + i) * 512 + lane * 8) = sp[i];
-    }
+    const int bwd[9][3] = {{OFF_TDIR, 8, 4}, {OFF_TFINAL, 8, 8}, {OFF_T8, 8, 8}, {OFF_T7, 8, 8}, {OFF_T6, 8, 8},
+                           {OFF_T5, 8, 8}, {OFF_T4, 8, 8}, {OFF_T3, 8, 8}, {OFF_T2, 8, 8}};
+    for (auto &f : bwd) add(f[0], f[1], f[2], FAST_FWD_UNITS + (f[0] - OFF_TRANS) / 512);
+    T.n = n;
+    T.n_units = FAST_FWD_UNITS + FAST_T_UNITS;
+    return T;
 }
 
 __device__ __forceinline__ void embed_xyz_blocks_f(float x, float y, float z, int half, f32x16 *e) {
@@ -271,7 +237,8 @@ size_t nerfmi_nerf_fast_bytes(void) { return (size_t)(FAST_FWD_UNITS + FAST_T_UN
 
 int nerfmi_nerf_pack_fast(const float *packed, void *fast, nerfmi_stream_t stream) {
     NERFMI_REQUIRE(packed && fast, "nerf_pack_fast: null pointer");
-    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, packed, (__bf16 *)fast);
+    hipLaunchKernelGGL(pack_bf16x3_table_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, nerf_fast_table(), packed,
+                       (__bf16 *)fast);
     return check_launch("nerf_pack_fast");
 }
 

@@ -7,7 +7,7 @@
 // FiLM epilogue  sin(freq * (W h + b) + phase)  runs on the VALU in four slices
 // per 32-unit block, placed between the next block's MFMAs (layer_mfma), so the
 // 2304 sines per point execute in the shadow of the matrix pipe.
-#include "mlp_core.h"
+#include "bf16x3_core.h"
 
 namespace nerfmi {
 
@@ -113,27 +113,136 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
     __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
     const int wid = threadIdx.x >> 6;
     const float *bias = packed + SOFF_BIAS + 4 * half;
-    f32x16 h[8], acc[8];
+    f32x16 hA[8], hB[8];                   // alternate: a layer reads one, its epilogue writes the other (no copies)
     WeightStage ws;
     // ring phases: network.0 is 2 stages, every hidden layer 16, so the hidden and color layers start at phase 2
-    layer_mfma_lds<1, 0, 8, 0, true>(packed + SOFF_L1, bias, e, nullptr, acc, no_pre, film_epi(0), wlds, ws, wid, lane);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) h[b] = acc[b];
-    for (int l = 1; l < 8; ++l) {
-        layer_mfma_lds<8, 0, 8, 2, false>(packed + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, h, nullptr, acc, no_pre, film_epi(l), wlds, ws, wid, lane);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) h[b] = acc[b];
-    }
-    const float sigma = dot_blocks<8>(h, packed + SOFF_W_SIGMA + 4 * half) + packed[SOFF_B_SIGMA];   // nerf.py:212
+    layer_mfma_lds<1, 0, 8, 0, true>(packed + SOFF_L1, bias, e, nullptr, hA, no_pre, film_epi(0), wlds, ws, wid, lane);
+    auto hidden = [&](int l, const f32x16 *in, f32x16 *out_h) __attribute__((always_inline)) {
+        layer_mfma_lds<8, 0, 8, 2, false>(packed + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, in, nullptr, out_h, no_pre,
+                                          film_epi(l), wlds, ws, wid, lane);
+    };
+    hidden(1, hA, hB);
+    hidden(2, hB, hA);
+    hidden(3, hA, hB);
+    hidden(4, hB, hA);
+    hidden(5, hA, hB);
+    hidden(6, hB, hA);
+    hidden(7, hA, hB);
+    const float sigma = dot_blocks<8>(hB, packed + SOFF_W_SIGMA + 4 * half) + packed[SOFF_B_SIGMA];   // nerf.py:212
     if (SIGMA_ONLY) {
         if (ok && half == 0) out[p] = sigma;
         return;
     }
-    layer_mfma_lds<1, 8, 8, 2, false>(packed + SOFF_COLOR, bias + 256 * 8, de, h, acc, no_pre, film_epi(8), wlds, ws, wid, lane);            // nerf.py:213
+    layer_mfma_lds<1, 8, 8, 2, false>(packed + SOFF_COLOR, bias + 256 * 8, de, hB, hA, no_pre, film_epi(8), wlds, ws, wid, lane);            // nerf.py:213
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float pre = dot_blocks<8>(acc, packed + SOFF_W_RGB + 256 * c + 4 * half) + packed[SOFF_B_RGB + c];
+        const float pre = dot_blocks<8>(hA, packed + SOFF_W_RGB + 256 * c + 4 * half) + packed[SOFF_B_RGB + c];
+        rgb[c] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-pre)));                                         // nerf.py:214
+    }
+    if (ok && half == 0) {
+        float4 o;
+        o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2]; o.w = sigma;
+        reinterpret_cast<float4 *>(out)[p] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// OPT-IN split-bf16 FiLM-SIREN forward (bf16x3_core.h).  The fp32 kernel spends a third of its time in the
+// sin(freq * (W h + b) + phase) epilogues because fp32 MFMAs do not overlap with the wave's own vector work; here a
+// layer's raw output is put through FiLM + sin by the layer that CONSUMES it, pair by pair between its XDL MFMAs,
+// which hide most of it.  Same packed parameters, same outputs, same tolerances.
+// ---------------------------------------------------------------------------------------------------
+static FastTable siren_fast_table() {
+    FastTable T;
+    int n = 0;
+    auto add = [&](int off, int JB, int KB) { T.l[n++] = FastLayer{off, JB, KB, off / 512}; };
+    add(SOFF_L1, 8, 1);
+    for (int l = 1; l < 8; ++l) add(SOFF_L2 + (l - 1) * SZ_HID, 8, 8);
+    add(SOFF_COLOR, 8, 9);
+    T.n = n;
+    T.n_units = SOFF_BIAS / 512;
+    return T;
+}
+constexpr int SIREN_FAST_UNITS = SOFF_BIAS / 512;
+
+template <bool SIGMA_ONLY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+siren_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__restrict__ fast,
+                            const float *__restrict__ rays, const float *__restrict__ z, const float *__restrict__ freq,
+                            const float *__restrict__ phase, int64_t n_points, int n_per_ray, int64_t points_per_cond,
+                            float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char wlds_fast[];
+    const int lane = threadIdx.x & 63, half = lane >> 5, wid = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t praw = wave * 32 + (lane & 31);
+    const bool ok = praw < n_points;
+    const int64_t p = ok ? praw : n_points - 1;
+    const float *rr = rays + (p / n_per_ray) * 8;
+    const float zz = z[p];
+    float x[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        x[c] = __fadd_rn(rr[c], __fmul_rn(rr[3 + c], zz));          // rendering.py:224-225
+        d[c] = rr[3 + c];
+    }
+    const float warp = 2.0f / 51.0f;                                 // UniformBoxWarp(51), nerf.py:134-140, :193
+    f32x16 e[1], de[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = 8 * (r >> 2) + 4 * half + (r & 3);
+        e[0][r] = (c < 3) ? __fmul_rn(x[c < 3 ? c : 0], warp) : 0.f;
+        de[0][r] = (c < 3) ? d[c < 3 ? c : 0] : 0.f;
+    }
+    const float *fq = freq + (p / points_per_cond) * 2304 + 4 * half;
+    const float *ph = phase + (p / points_per_cond) * 2304 + 4 * half;
+    // FiLM + sin of the pair (registers 2p, 2p+1 of block kb) of layer `layer`'s raw output (nerf.py:151, :202)
+    auto film = [fq, ph](int layer, int kb, int pr, float &x0, float &x1) {
+        const int r = 2 * pr;
+        const int u = 256 * layer + 32 * kb + 8 * (r >> 2) + (r & 3);
+        const float2 f = *reinterpret_cast<const float2 *>(fq + u), s = *reinterpret_cast<const float2 *>(ph + u);
+        x0 = sin_cw(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.x, 15.0f), 30.0f), x0), s.x));
+        x1 = sin_cw(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.y, 15.0f), 30.0f), x1), s.y));
+    };
+    auto film_hook = [&film](int layer) {
+        return [&film, layer](int kb, int pr, float &x0, float &x1) { film(layer, kb, pr, x0, x1); };
+    };
+    auto film_all = [&film](int layer, f32x16 *h) {                  // a whole layer's output at once (no consumer layer)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) {
+                float x0 = h[b][2 * pr], x1 = h[b][2 * pr + 1];
+                film(layer, b, pr, x0, x1);
+                h[b][2 * pr] = x0; h[b][2 * pr + 1] = x1;
+            }
+    };
+    const float *bias = packed + SOFF_BIAS + 4 * half;
+    auto img = [&](int off) { return fast + fast_fwd_elems(off); };
+    f32x16 hA[8], hB[8];
+    FastStage fs;
+    NoHook none;
+    // ring phases: network.0 is 2 stages, every hidden layer 16, so the hidden and color layers start at phase 2
+    layer_bf16x3<1, 0, 8, false, true, NoHook, NoHook, 0>(img(SOFF_L1), bias, e, nullptr, hA, wlds_fast, fs, wid, lane);
+    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 0 * SZ_HID), bias + 256 * 1, nullptr, hA, hB, wlds_fast, fs, wid, lane, none, film_hook(0));
+    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 1 * SZ_HID), bias + 256 * 2, nullptr, hB, hA, wlds_fast, fs, wid, lane, none, film_hook(1));
+    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 2 * SZ_HID), bias + 256 * 3, nullptr, hA, hB, wlds_fast, fs, wid, lane, none, film_hook(2));
+    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 3 * SZ_HID), bias + 256 * 4, nullptr, hB, hA, wlds_fast, fs, wid, lane, none, film_hook(3));
+    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 4 * SZ_HID), bias + 256 * 5, nullptr, hA, hB, wlds_fast, fs, wid, lane, none, film_hook(4));
+    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 5 * SZ_HID), bias + 256 * 6, nullptr, hB, hA, wlds_fast, fs, wid, lane, none, film_hook(5));
+    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 6 * SZ_HID), bias + 256 * 7, nullptr, hA, hB, wlds_fast, fs, wid, lane, none, film_hook(6));
+    film_all(7, hB);                                                  // network.7's output feeds sigma and the colour layer
+    const float sigma = dot_blocks<8>(hB, packed + SOFF_W_SIGMA + 4 * half) + packed[SOFF_B_SIGMA];   // nerf.py:212
+    if (SIGMA_ONLY) {
+        if (ok && half == 0) out[p] = sigma;
+        return;
+    }
+    layer_bf16x3<1, 8, 8, false, false, NoHook, NoHook, 2>(img(SOFF_COLOR), bias + 256 * 8, de, hB, hA, wlds_fast, fs, wid, lane);   // nerf.py:213
+    film_all(8, hA);
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float pre = dot_blocks<8>(hA, packed + SOFF_W_RGB + 256 * c + 4 * half) + packed[SOFF_B_RGB + c];
         rgb[c] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-pre)));                                         // nerf.py:214
     }
     if (ok && half == 0) {
@@ -198,6 +307,46 @@ int nerfmi_siren_forward_rays(const float *packed, const float *rays, const floa
         hipLaunchKernelGGL((siren_forward_kernel<true, false>), grid, block, 0, st, packed, rays, z, nullptr, nullptr,
                            frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out);
     return check_launch("siren_forward_rays");
+}
+
+size_t nerfmi_siren_fast_bytes(void) { return (size_t)SIREN_FAST_UNITS * 3072 + FAST_TAIL_BYTES; }
+
+int nerfmi_siren_pack_fast(const float *packed, void *fast, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(packed && fast, "siren_pack_fast: null pointer");
+    hipLaunchKernelGGL(pack_bf16x3_table_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, siren_fast_table(), packed,
+                       (__bf16 *)fast);
+    return check_launch("siren_pack_fast");
+}
+
+int nerfmi_siren_forward_rays_fast(const float *packed, const void *fast, const float *rays, const float *z,
+                                   const float *frequencies, const float *phase_shifts, int n_rays, int n_per_ray,
+                                   int64_t rays_per_cond, int sigma_only, float *out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && rays_per_cond >= 1, "siren_forward_rays_fast: bad sizes");
+    const int64_t n_points = (int64_t)n_rays * n_per_ray;
+    if (n_points == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(packed && fast && rays && z && frequencies && phase_shifts && out, "siren_forward_rays_fast: null pointer");
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(siren_forward_bf16x3_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(siren_forward_bf16x3_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("siren_forward_rays_fast: cannot raise the dynamic LDS limit");
+            return NERFMI_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int64_t waves = (n_points + 31) / 32;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (sigma_only)
+        hipLaunchKernelGGL((siren_forward_bf16x3_kernel<true>), grid, block, FLDS_BYTES, st, packed, (const __bf16 *)fast,
+                           rays, z, frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out);
+    else
+        hipLaunchKernelGGL((siren_forward_bf16x3_kernel<false>), grid, block, FLDS_BYTES, st, packed, (const __bf16 *)fast,
+                           rays, z, frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out);
+    return check_launch("siren_forward_rays_fast");
 }
 
 }  // extern "C"

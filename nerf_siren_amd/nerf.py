@@ -174,6 +174,14 @@ class SemanticNeRF(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def packed_fast(self):
+        """bf16x3 split image for the opt-in fast math (rendering.set_math('bf16x3'))."""
+        pk = self.packed()
+        if getattr(self, "_fast_key", None) is not self._packed_key or getattr(self, "_fast", None) is None:
+            self._fast = ops.siren_pack_fast(pk)
+            self._fast_key = self._packed_key
+        return self._fast
+
     def forward(self, input, z, ray_directions, **kwargs):
         # the reference calls self.mapping_network, which it never defines (nerf.py:185 is commented out)
         raise AttributeError("'SemanticNeRF' object has no attribute 'mapping_network' (models/nerf.py:185, :198); "
@@ -206,5 +214,9 @@ class SirenField(nn.Module):
                                          requires_grad=False)
 
     def field_rays(self, rays, z, sigma_only=False):
+        from .rendering import get_math
+        if get_math() == "bf16x3":
+            return ops.siren_forward_rays_fast(self.model.packed(), self.model.packed_fast(), rays, z, self.frequencies,
+                                               self.phase_shifts, rays.shape[0], sigma_only)
         return ops.siren_forward_rays(self.model.packed(), rays, z, self.frequencies, self.phase_shifts,
                                       rays.shape[0], sigma_only)

@@ -218,6 +218,27 @@ def siren_forward_rays(packed, rays, z, freq, phase, rays_per_cond, sigma_only=F
     return out
 
 
+def siren_pack_fast(packed):
+    fast = torch.empty(_lib.lib().nerfmi_siren_fast_bytes(), device=packed.device, dtype=torch.uint8)
+    check(_lib.lib().nerfmi_siren_pack_fast(ptr(packed), ptr(fast), _stream(packed)), "siren_pack_fast")
+    return fast
+
+
+def siren_forward_rays_fast(packed, fast, rays, z, freq, phase, rays_per_cond, sigma_only=False):
+    rays = _req(rays, "rays", (None, 8))
+    z = _req(z, "z", (rays.shape[0], None))
+    n, p = z.shape
+    freq = _req(freq, "frequencies", (None, 2304))
+    phase = _req(phase, "phase_shifts", (freq.shape[0], 2304))
+    if freq.shape[0] * rays_per_cond < n:
+        raise ValueError("frequencies has too few rows for the rays")
+    out = torch.empty((n * p, 1 if sigma_only else 4), device=rays.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_siren_forward_rays_fast(ptr(packed), ptr(fast), ptr(rays), ptr(z), ptr(freq), ptr(phase), n, p,
+                                                    int(rays_per_cond), int(bool(sigma_only)), ptr(out), _stream(rays)),
+          "siren_forward_rays_fast")
+    return out
+
+
 # --------------------------------------------------------------------------- a8
 def composite(field, z, rays, noise=None, noise_std=0.0, white_back=False, sigma_only=False, want_weights=True):
     rays = _req(rays, "rays", (None, 8))

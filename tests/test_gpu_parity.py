@@ -455,10 +455,14 @@ def test_siren_forward_vs_reference(golden, dev, siren):
         m.forward(T(g["inp"], dev), None, T(g["dirs"], dev))
 
 
-def test_siren_render_rays(dev, siren, ops):
-    """SIREN field behind render_rays (coarse+fine, test_time and full) against the oracle pipeline."""
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+def test_siren_render_rays(dev, siren, ops, math):
+    """SIREN field behind render_rays (coarse+fine, test_time and full) against the oracle pipeline; math = bf16x3: the
+    opt-in split-bf16 kernel (FiLM + sin applied by the consuming layer), same tolerances."""
+    import nerf_siren_amd
     from nerf_siren_amd import Embedding, SirenField, render_rays
     p, m = siren
+    nerf_siren_amd.set_math(math)
     freq, phase = synth.hash_normal((1, 2304), 301), synth.hash_normal((1, 2304), 302)
     f = SirenField(m, T(freq, dev), T(phase, dev)).to(dev)
     rays = synth.blender_rays(37, 33)
@@ -477,6 +481,17 @@ def test_siren_render_rays(dev, siren, ops):
     np.testing.assert_allclose(N(rt["opacity_coarse"]), cc["opacity"], atol=2e-5)
     assert list(rt.keys()) == ["opacity_coarse", "rgb_fine", "depth_fine", "opacity_fine"]
     assert torch.isfinite(res["rgb_fine"]).all() and (res["opacity_fine"] <= 1 + 1e-5).all()
+    nerf_siren_amd.set_math("fp32")
+    if math == "bf16x3":
+        # field values of both kernels on the same points
+        zz = T(z, dev)
+        a = ops.siren_forward_rays(m.packed(), T(rays, dev), zz, T(freq, dev), T(phase, dev), 37)
+        b = ops.siren_forward_rays_fast(m.packed(), m.packed_fast(), T(rays, dev), zz, T(freq, dev), T(phase, dev), 37)
+        np.testing.assert_allclose(N(b), N(a), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(N(b).reshape(37, 64, 4), o1, rtol=3e-5, atol=3e-5)
+        sa = ops.siren_forward_rays_fast(m.packed(), m.packed_fast(), T(rays, dev), zz, T(freq, dev), T(phase, dev), 37,
+                                         sigma_only=True)
+        np.testing.assert_allclose(N(sa)[:, 0], N(b)[:, 3], rtol=0, atol=1e-6)
     with pytest.raises(NotImplementedError):
         render_rays([f, f], emb, T(rays, dev), 64, False, 0, 0, 64, 1024 * 32, True, False)   # grad mode
 
