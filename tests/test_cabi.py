@@ -47,6 +47,21 @@ def test_argument_validation_without_gpu(libpath):
     assert l.nerfmi_searchsorted(None, None, 3, 2, 5, 5, 0, None, None) == -1
     assert b"broadcast" in l.nerfmi_last_error()
     assert l.nerfmi_sample_stratified(None, None, 0, 64, 0, 0.0, None, None) == 0      # empty batch is a no-op
+    # the entry points added around the path (f1 / f2) and the opt-in math validate the same way
+    assert l.nerfmi_mse_loss(None, None, None, 12, 1.0, None, None, None, None) == -1 and b"null" in l.nerfmi_last_error()
+    assert l.nerfmi_mse_loss(None, None, None, 0, 1.0, None, None, None, None) == -1
+    assert l.nerfmi_adam_step(None, None, None, None, 8, 5e-4, 0.9, 0.999, 1e-8, 0.0, 0, 1.0, None) == -1   # step >= 1
+    assert l.nerfmi_adam_step(None, None, None, None, 8, 5e-4, 0.4, 0.999, 1e-8, 0.0, 1, 1.0, None) == -1   # null, beta1
+    assert l.nerfmi_adam_step(None, None, None, None, 0, 5e-4, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None) == 0    # empty
+    assert l.nerfmi_generate_rays(None, 1, 4, 4, 5.0, None, 7, 0, 2.0, 6.0, None, None) == -1
+    assert b"n_images*H*W" in l.nerfmi_last_error()
+    assert l.nerfmi_generate_rays(None, 1, 4, 4, -1.0, None, 16, 0, 2.0, 6.0, None, None) == -1
+    assert l.nerfmi_ray_directions(0, 4, 5.0, None, None) == -1
+    assert l.nerfmi_get_rays(None, None, 0, None, None, None) == 0
+    assert l.nerfmi_nerf_forward_rays_fast(None, None, None, None, 4, 8, 0, None, None, None) == -1
+    assert l.nerfmi_nerf_backward_rays_fast(None, None, 4, 8, None, None, None, None, None) == -1
+    assert l.nerfmi_siren_forward_rays_fast(None, None, None, None, None, None, 0, 8, 1, 0, None, None) == 0
+    assert l.nerfmi_nerf_fast_bytes() > 3 * 2 * 1100000 and l.nerfmi_siren_fast_bytes() > 3 * 2 * 500000
 
 
 def test_python_api_mirrors_reference_signature():
