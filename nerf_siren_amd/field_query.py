@@ -22,9 +22,9 @@ from . import ops
 def query_field(model, xyz, dirs=None, sigma_only=False, chunk=1 << 22):
     """xyz (B,3) fp32 on the GPU, dirs (B,3) or None (= zeros, 'sigma is independent of direction',
     extract_color_mesh.py:124) -> (B,4) [rgb, sigma] or (B,1) sigma."""
+    from .rendering import _field_infer          # honours set_math('bf16x3')
     xyz = xyz.reshape(-1, 3).float().contiguous()
     B = xyz.shape[0]
-    packed = model.packed()
     outs = []
     for i in range(0, B, chunk):
         x = xyz[i:i + chunk]
@@ -34,7 +34,7 @@ def query_field(model, xyz, dirs=None, sigma_only=False, chunk=1 << 22):
         if dirs is not None:
             rays[:, 3:6] = dirs.reshape(-1, 3)[i:i + chunk]
         z = torch.zeros((n, 1), device=x.device, dtype=torch.float32)
-        out = ops.nerf_forward_rays(packed, rays, z, sigma_only=sigma_only)
+        out = _field_infer(model, rays, z, sigma_only)
         outs.append(out.reshape(n, -1))
     return torch.cat(outs, 0) if len(outs) != 1 else outs[0]
 
