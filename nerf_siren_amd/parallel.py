@@ -3,7 +3,8 @@ all-reduce(mean) of the flat fp32 gradient per step (RCCL over xGMI).
 
 Counterpart of train.py:48-49 (Lightning DDP) for the renderer: the only exchange
 step of the path is the parameter gradient (2 x 595 844 fp32 = 4 766 752 B).  Both
-models' gradients live in ONE contiguous buffer (every p.grad is a view into it),
+models' gradients live in ONE contiguous buffer (FlatGradAllReduce.joint: the HIP backward
+of model i writes slice i, every p.grad is a view into it),
 so the collective is a single ncclAllReduce -- at this size RCCL is latency bound
 on the fully connected xGMI mesh, and one call beats per-tensor or bucketed calls.
 """
@@ -45,6 +46,20 @@ class FlatGradAllReduce:
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.group = group
         self.flat = None
+        # ONE buffer for the gradients of all models: the HIP backward of model i writes into slice i
+        # (rendering.FieldRender reads model._grad_target), so the step's exchange is a single collective
+        self.joint = None
+        try:
+            from . import ops
+            ps0 = [p for m in self.models for p in m.parameters()]
+            if ps0 and all(hasattr(m, "param_list") and sum(p.numel() for p in m.parameters()) == ops.PARAM_NUMEL
+                           for m in self.models) and all(p.is_cuda for p in ps0):
+                n = ops.PARAM_NUMEL
+                self.joint = torch.empty(len(self.models) * n, device=ps0[0].device, dtype=torch.float32)
+                for i, m in enumerate(self.models):
+                    m._grad_target = self.joint[i * n:(i + 1) * n]
+        except Exception:                       # foreign modules: per-model / loose paths below
+            self.joint = None
 
     def _bases(self):
         bases, loose = [], []
@@ -69,6 +84,13 @@ class FlatGradAllReduce:
         average=False leaves the SUM in the buffers: the caller folds 1/world into the optimizer
         (training.FusedAdam.step(grad_scale=1/world)) and saves a pass over the gradients."""
         bases, loose = self._bases()
+        if self.joint is not None and not loose and len(bases) == len(self.models) and all(
+                b.data_ptr() == m._grad_target.data_ptr() for b, m in zip(bases, self.models)):
+            if self.world > 1:                  # every model's gradients sit in the joint buffer: one collective
+                dist.all_reduce(self.joint, op=dist.ReduceOp.SUM, group=self.group)
+                if average:
+                    self.joint.mul_(1.0 / self.world)
+            return [self.joint]
         if self.world > 1:
             for b in bases:
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)

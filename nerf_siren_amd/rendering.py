@@ -62,6 +62,7 @@ class FieldRender(torch.autograd.Function):
         ctx.save_for_backward(rays, z, noise if noise is not None else rays.new_empty(0), field, saved, packed)
         ctx.cfg = (noise is not None, float(noise_std), bool(white_back))
         ctx.fast = model.packed_fast() if _MATH == "bf16x3" else None
+        ctx.model = model
         ctx.mark_non_differentiable(weights)
         ctx.set_materialize_grads(False)        # absent d/d(depth, opacity) arrive as None -> NULL in the C ABI
         return rgb, depth, opacity, weights
@@ -74,7 +75,16 @@ class FieldRender(torch.autograd.Function):
             return (None,) * (6 + len(ops.PARAM_ORDER))
         grad_field = ops.composite_backward(field, z, rays, noise if has_noise else None, noise_std, white_back,
                                             g_rgb, g_depth, g_opacity)
-        grads = ops.nerf_backward_rays(packed, rays, z, saved, grad_field, fast=ctx.fast)
+        # A data-parallel reducer may have given the model a slice of ONE buffer shared by all models
+        # (parallel.FlatGradAllReduce): write the gradients there, unless a parameter still holds a gradient in that very
+        # memory (zero_grad(set_to_none=False) / accumulation), in which case autograd must add into a fresh buffer.
+        target = getattr(ctx.model, "_grad_target", None)
+        out = None
+        if target is not None and target.device == rays.device:
+            lo, hi = target.data_ptr(), target.data_ptr() + target.numel() * 4
+            if not any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in ctx.model.parameters()):
+                out = ops.flat_views(target)
+        grads = ops.nerf_backward_rays(packed, rays, z, saved, grad_field, grads=out, fast=ctx.fast)
         return (None, None, None, None, None, None, *grads)
 
 

@@ -990,3 +990,47 @@ def test_render_rays_edge_batches(dev, models):
         for m in tr:
             for name, q in m.named_parameters():
                 assert q.grad is not None and torch.isfinite(q.grad).all(), name
+
+
+# --------------------------------------------------------------------------- data-parallel gradient buffer
+def test_joint_gradient_buffer(dev, models):
+    """parallel.FlatGradAllReduce hands every model a slice of ONE buffer; the HIP backward writes there (a single
+    collective per step), gradients are bit-identical to the un-shared path, and accumulation into existing .grad
+    (zero_grad(set_to_none=False)) still adds instead of aliasing."""
+    from nerf_siren_amd import Embedding, NeRF, render_rays
+    from nerf_siren_amd.parallel import FlatGradAllReduce
+    params, _ = models
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    rays = T(synth.blender_rays(40, 8), dev)
+    rg = {k: T(v, dev) for k, v in synth.psnr_step_rng(0, 40, 64, 64).items()}
+
+    def fresh():
+        ms = []
+        for p in params:
+            m = NeRF()
+            m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+            ms.append(m.to(dev))
+        return ms
+
+    def backward(ms):
+        res = render_rays(ms, emb, rays, 64, False, 1.0, 0.0, 64, 1 << 15, True, False, rng=rg)
+        (res["rgb_coarse"].square().mean() + res["rgb_fine"].square().mean()).backward()
+
+    plain = fresh()
+    backward(plain)
+    shared = fresh()
+    red = FlatGradAllReduce(shared, 1)
+    assert red.joint is not None and red.joint.numel() == 2 * 595844
+    backward(shared)
+    bases = red.all_reduce()
+    assert len(bases) == 1 and bases[0] is red.joint
+    for a, b in zip(plain, shared):
+        for (k, p), q in zip(a.named_parameters(), b.parameters()):
+            assert torch.equal(p.grad, q.grad), k
+            lo = red.joint.data_ptr()
+            assert lo <= q.grad.data_ptr() < lo + red.joint.numel() * 4
+    # second backward WITHOUT clearing the gradients: autograd must accumulate (2x), not alias the target
+    backward(shared)
+    for a, b in zip(plain, shared):
+        for (k, p), q in zip(a.named_parameters(), b.parameters()):
+            np.testing.assert_allclose(N(q.grad), 2 * N(p.grad), rtol=1e-6, atol=1e-12, err_msg=k)
