@@ -570,3 +570,23 @@ def pack_vol(rgbsigma, N, extent):
     a = a[i]
     s = rgb.dot(np.array([1 << 24, 1 << 16, 1 << 8])) + (a * 255).astype(np.uint32)
     return np.stack([i, s], -1).astype(np.uint32).flatten()
+
+
+# ----------------------------------------------------------------------------
+# Arithmetic of the opt-in split-bf16 kernels (csrc/bf16x3_core.h), restated for CPU tests
+# ----------------------------------------------------------------------------
+def bf16_round(x):
+    """fp32 -> nearest bf16 (ties to even), returned as fp32 (v_cvt_pk_bf16_f32)."""
+    b = np.asarray(x, F32).view(np.uint32).astype(np.uint64)
+    b = (b + 0x7FFF + ((b >> 16) & 1)) & 0xFFFF0000
+    return b.astype(np.uint32).view(F32)
+
+
+def split3(x):
+    """x = p0 + p1 + p2 with three bf16 terms (each residual is exact in fp32)."""
+    x = np.asarray(x, F32)
+    p0 = bf16_round(x)
+    r1 = (x - p0).astype(F32)
+    p1 = bf16_round(r1)
+    r2 = (r1 - p1).astype(F32)
+    return p0, p1, bf16_round(r2)

@@ -324,3 +324,24 @@ def test_pfm_writer_matches_reference_bytes(golden, tmp_path):
             assert np.array_equal(back, g["img_" + tag])
     with pytest.raises(Exception):
         save_pfm(str(tmp_path / "bad.pfm"), np.zeros((2, 2), np.float64))
+
+
+# --------------------------------------------------------------------------- split-bf16 arithmetic (opt-in math)
+def test_bf16_three_way_split_is_exact():
+    """The claim behind csrc/bf16x3_core.h: an fp32 value is EXACTLY the sum of three bf16 terms (round-to-nearest at
+    each step), and the six kept products a1b1+a1b2+a2b1+a2b2+a1b3+a3b1 miss the exact product by <= ~2^-23 of it."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(200000) * 10.0 ** rng.integers(-20, 20, 200000),
+                        [0.0, -0.0, 1.0, -1.0, 3.0e38, 2.0 ** -100, 1 + 2.0 ** -23, 255.99998, 16777215.0]]).astype(np.float32)
+    # (values whose residuals would be subnormal, |x| < 2^-102, are outside the claim: the kernels flush them)
+    p0, p1, p2 = O.split3(x)
+    assert np.array_equal((p0.astype(np.float64) + p1.astype(np.float64)) + p2.astype(np.float64), x.astype(np.float64))
+    for p in (p0, p1, p2):                                   # each term really is a bf16 number
+        assert np.all(p.view(np.uint32) & 0xFFFF == 0)
+    a, b = x[:100000], x[100000:200000]
+    a1, a2, a3 = (t.astype(np.float64) for t in O.split3(a))
+    b1, b2, b3 = (t.astype(np.float64) for t in O.split3(b))
+    kept = a1 * b1 + a1 * b2 + a2 * b1 + a2 * b2 + a1 * b3 + a3 * b1
+    exact = a.astype(np.float64) * b.astype(np.float64)
+    ok = np.isfinite(exact) & (np.abs(exact) > 1e-30) & (np.abs(exact) < 1e30)
+    assert np.abs(kept[ok] / exact[ok] - 1).max() < 2.0 ** -22
