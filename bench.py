@@ -48,6 +48,7 @@ def parse():
                     help="training: nerf_siren_amd.training.FusedAdam + FusedMSELoss (one launch each) or torch.optim.Adam "
                          "+ elementwise loss -- same arithmetic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-psnr", action="store_true", help="skip the PSNR-parity check (tests/golden/g15_psnr.npz protocol)")
     ap.add_argument("--no-opt-in", action="store_true", help="skip the extra timed loop on the opt-in split-bf16 math")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work in the bounded cpu_baseline sample")
     return ap.parse_args()
@@ -84,6 +85,51 @@ def cpu_baseline(mode, budget_s=12.0, chunk=256, max_rays=8192):
     return {"value": done * 192 / dt, "unit": "ray-samples/s", "cores": int(cores), "kind": "port",
             "sample": f"{done} rays x (64+128) samples in chunks of {chunk}, {mode} step "
                       f"(fwd{'+bwd' if mode == 'train' else ''}), numpy oracle, {dt:.1f} s"}
+
+
+def psnr_check(dev):
+    """The metric's '+ PSNR': the reference trained 240 Adam steps on a teacher scene on CPU and its validation-PSNR
+    trajectory is a committed fixture (tools/make_psnr_golden.py -> tests/golden/g15_psnr.npz); the same steps (same
+    images, batches, injected draws, initial weights) run here on the HIP path.  A few seconds; rank 0 at N = 1 only."""
+    import numpy as np
+    import torch
+    from nerf_siren_amd import Embedding, NeRF, render_rays, synth
+    from nerf_siren_amd.training import FusedAdam, FusedMSELoss
+    path = os.path.join(ROOT, "tests", "golden", "g15_psnr.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    S, F, B = int(g["cfg_S"]), int(g["cfg_F"]), int(g["cfg_batch"])
+    steps, every = int(g["cfg_steps"]), int(g["cfg_eval_every"])
+    ms = []
+    for seed in (11, 12):
+        m = NeRF()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
+        ms.append(m.to(dev))
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)          # noqa: E731
+    rays, tgt, val_rays, val_tgt = T(g["rays"]), T(g["target"]), T(g["val_rays"]), T(g["val_target"])
+    opt, loss_fn = FusedAdam(ms, lr=float(g["cfg_lr"]), eps=1e-8), FusedMSELoss(unit_grad=True)
+    psnr = []
+    for step in range(steps + 1):
+        if step % every == 0:
+            with torch.no_grad():
+                r = render_rays(ms, emb, val_rays, S, False, 0, 0, F, 1 << 15, True, False)
+            psnr.append(float(-10 * torch.log10(((r["rgb_fine"] - val_tgt) ** 2).mean())))
+        if step == steps:
+            break
+        idx = torch.from_numpy(synth.psnr_batch_indices(step, rays.shape[0], B)).to(dev)
+        rg = {k: T(v) for k, v in synth.psnr_step_rng(step, B, S, F).items()}
+        res = render_rays(ms, emb, rays[idx], S, False, 1.0, 0.0, F, 1 << 15, True, False, rng=rg)
+        loss = loss_fn(res, tgt[idx])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    ref = [float(v) for v in g["psnr"]]
+    return {"value_db": psnr[-1], "reference_db": ref[-1], "max_abs_diff_db": float(np.abs(np.array(psnr) - ref).max()),
+            "trajectory_db": [round(v, 3) for v in psnr], "reference_trajectory_db": [round(v, 3) for v in ref],
+            "protocol": f"teacher scene, {steps} Adam steps of {B} rays ({S}+{F}), validation every {every} steps; "
+                        "reference = /root/reference on CPU (tests/golden/g15_psnr.npz)"}
 
 
 def main():
@@ -312,6 +358,8 @@ def main():
         }
         if opt_in is not None:
             out["opt_in"] = opt_in
+        if world == 1 and train and not siren and not args.no_psnr:
+            out["psnr"] = psnr_check(dev)
         if world == 1 and not args.no_cpu_baseline and not siren:
             out["cpu_baseline"] = cpu_baseline(args.mode, budget_s=args.cpu_seconds)
         print(json.dumps(out), flush=True)
