@@ -1,4 +1,5 @@
-// OPT-IN fast math for the NeRF MLP forward on gfx950: fp32-equivalent products on the bf16 matrix cores.
+// OPT-IN fast math for the NeRF MLP forward (inference, and training with saved activations) on gfx950:
+// fp32-equivalent products on the bf16 matrix cores.  (Backward: mlp_bwd.hip sections 1b and 2b; layer: bf16x3_core.h.)
 //
 // gfx950 has no TF32/xf32; its exact-fp32 MFMA runs at 1/16 of the bf16 rate.  An fp32 value splits EXACTLY
 // into three bf16 terms (x = x1 + x2 + x3, 3 x 8 significant bits, round-to-nearest at each step), and a

@@ -14,6 +14,7 @@
 //     into chunks (split-K) and every workgroup writes its partial slab.
 //  3. nerf_dw_reduce_kernel -- deterministic slab reduction into the (out,in)
 //     gradient tensors (no float atomics: results are bit-reproducible).
+//  1b / 2b. the same chain and GEMM on the opt-in split-bf16 math (bf16x3_core.h): same images in and out.
 #include "bf16x3_core.h"
 
 namespace nerfmi {
