@@ -1034,3 +1034,33 @@ def test_joint_gradient_buffer(dev, models):
     for a, b in zip(plain, shared):
         for (k, p), q in zip(a.named_parameters(), b.parameters()):
             np.testing.assert_allclose(N(q.grad), 2 * N(p.grad), rtol=1e-6, atol=1e-12, err_msg=k)
+
+
+# --------------------------------------------------------------------------- README example
+def test_readme_training_loop(dev):
+    """The training loop of README.md: device ray generation -> render_rays -> fused loss -> fused Adam, both maths."""
+    import nerf_siren_amd
+    from nerf_siren_amd import NeRF, Embedding, render_rays, generate_rays, FusedAdam, FusedMSELoss
+    torch.manual_seed(0)
+    models = [NeRF().to(dev), NeRF().to(dev)]
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    opt, loss_fn = FusedAdam(models, lr=5e-4, eps=1e-8), FusedMSELoss(unit_grad=True)
+    c2w = T(np.stack([synth._look_at_c2w(0.3, 0.2 * k, 4.03) for k in range(4)]).astype(np.float32), dev)
+    H = W = 50
+    losses = []
+    try:
+        for it in range(6):
+            nerf_siren_amd.set_math("bf16x3" if it >= 3 else "fp32")
+            pixel_index = torch.randint(0, 4 * H * W, (256,), device=dev)
+            rgb = T(synth.hash_uniform((256, 3), 40), dev)
+            rays = generate_rays(c2w, H, W, 69.4, pixel_index)
+            res = render_rays(models, emb, rays, 64, False, 1.0, 1.0, 64, 32768, True)
+            loss = loss_fn(res, rgb)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+            assert np.isfinite(losses[-1]) and np.isfinite(float(loss_fn.psnr))
+    finally:
+        nerf_siren_amd.set_math("fp32")
+    assert losses[-1] < losses[0]
