@@ -109,6 +109,32 @@ class FusedAdam(torch.optim.Optimizer):
                 e["scratch"][o:o + k].copy_(p.grad.reshape(-1))
         return e["scratch"]
 
+    # checkpoint / resume: the moments live in flat buffers outside torch's per-parameter state
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["fused"] = {"n_steps": self._n_steps,
+                       "exp_avg": [e["exp_avg"].clone() for e in self._entries],
+                       "exp_avg_sq": [e["exp_avg_sq"].clone() for e in self._entries]}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        fused = state_dict.get("fused")
+        if fused is None:
+            raise ValueError("not a FusedAdam state_dict (no 'fused' entry)")
+        if len(fused["exp_avg"]) != len(self._entries):
+            raise ValueError("FusedAdam.load_state_dict: different number of models")
+        for g, saved in zip(self.param_groups, state_dict["param_groups"]):
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if k in saved:
+                    g[k] = saved[k]
+            if "initial_lr" in saved:
+                g["initial_lr"] = saved["initial_lr"]
+        with torch.no_grad():
+            for e, m, v in zip(self._entries, fused["exp_avg"], fused["exp_avg_sq"]):
+                e["exp_avg"].copy_(m.to(e["exp_avg"].device))
+                e["exp_avg_sq"].copy_(v.to(e["exp_avg_sq"].device))
+        self._n_steps = int(fused["n_steps"])
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = None

@@ -1064,3 +1064,46 @@ def test_readme_training_loop(dev):
     finally:
         nerf_siren_amd.set_math("fp32")
     assert losses[-1] < losses[0]
+
+
+def test_fused_adam_checkpoint_resume(dev, models, tmp_path):
+    """FusedAdam.state_dict()/load_state_dict(): 3 steps + save + resume in fresh objects + 2 steps == 5 steps."""
+    from nerf_siren_amd import Embedding, NeRF, render_rays
+    from nerf_siren_amd.training import FusedAdam, FusedMSELoss
+    params, _ = models
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    rays = T(synth.blender_rays(48, 15), dev)
+    tgt = T(synth.hash_uniform((48, 3), 16), dev)
+
+    def fresh():
+        ms = []
+        for p in params:
+            m = NeRF()
+            m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+            ms.append(m.to(dev))
+        return ms, FusedAdam(ms, lr=1e-3, eps=1e-8)
+
+    def run(ms, opt, a, b):
+        loss_fn = FusedMSELoss(unit_grad=True)
+        for step in range(a, b):
+            rg = {k: T(v, dev) for k, v in synth.psnr_step_rng(step, 48, 64, 64).items()}
+            res = render_rays(ms, emb, rays, 64, False, 1.0, 0.0, 64, 1 << 15, True, False, rng=rg)
+            loss = loss_fn(res, tgt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+    ms_a, opt_a = fresh()
+    run(ms_a, opt_a, 0, 5)
+    ms_b, opt_b = fresh()
+    run(ms_b, opt_b, 0, 3)
+    torch.save({"models": [m.state_dict() for m in ms_b], "opt": opt_b.state_dict()}, tmp_path / "ck.pt")
+    ck = torch.load(tmp_path / "ck.pt", map_location="cpu", weights_only=False)
+    ms_c, opt_c = fresh()
+    for m, sd in zip(ms_c, ck["models"]):
+        m.load_state_dict(sd)
+    opt_c.load_state_dict(ck["opt"])
+    run(ms_c, opt_c, 3, 5)
+    for a, c in zip(ms_a, ms_c):
+        for (k, p), q in zip(a.named_parameters(), c.parameters()):
+            assert torch.equal(p, q), k
