@@ -171,7 +171,8 @@ int nerfmi_merge_sorted(const float *za, const float *zb, int n_rays, int na, in
                         nerfmi_stream_t stream);
 
 /* rendering.py:242-247 fused: z_mid -> sample_pdf(z_mid, w[:,1:-1]) -> sort(cat).
- * z_coarse (n_rays,S), weights_coarse (n_rays,S), u NULL => det.
+ * z_coarse (n_rays,S) (any order; ascending input -- what the stratified sampler produces -- takes the fast
+ * rank-merge path), weights_coarse (n_rays,S), u NULL => det.
  * z_fine_out (n_rays,S+F).  z_new_out optional (n_rays,F). */
 int nerfmi_importance_resample(const float *z_coarse, const float *weights_coarse, const float *u, int n_rays,
                                int n_samples, int n_importance, float *z_new_out, float *z_fine_out,

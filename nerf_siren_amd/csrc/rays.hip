@@ -360,8 +360,47 @@ importance_resample_kernel(const float *__restrict__ zc, const float *__restrict
             if (z_new_out) z_new_out[(int64_t)r * F + f] = s;
         }
         __syncthreads();
-        bitonic_sort_lds(srt, npad, lane);
-        for (int k = lane; k < n; k += WAVE) z_fine_out[(int64_t)r * n + k] = srt[k];
+        // the coarse run is sorted when it comes from the stratified sampler (always, in render_rays); checked, because
+        // the rank merge below relies on it and the reference sorts the concatenation whatever its input
+        bool sorted_run = true;
+        for (int k = lane; k + 1 < S; k += WAVE) sorted_run = sorted_run && (srt[k] <= srt[k + 1]);
+        if (F <= WAVE && __all(sorted_run)) {
+            // sort(cat[z_coarse (already sorted), z_new]) without sorting 128 keys through LDS: the F <= 64 new depths
+            // are sorted in registers, one per lane (21 compare-exchange steps by cross-lane shuffles), then every
+            // depth goes straight to its rank = own index + number of depths of the OTHER run in front of it
+            // (binary searches; "<=" on one side and "<" on the other make the ranks of equal values distinct).
+            float v = lane < F ? srt[S + lane] : INFINITY;
+            for (int k = 2; k <= WAVE; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    const float o = __shfl_xor(v, j, WAVE);
+                    const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+                    v = keep_min ? fminf(v, o) : fmaxf(v, o);
+                }
+            __syncthreads();
+            if (lane < F) srt[S + lane] = v;                     // the sorted new depths replace the unsorted ones
+            __syncthreads();
+            auto new_at = [&](int i) { return srt[S + i]; };
+            if (lane < F) {                                      // rank of this new depth: coarse depths <= it
+                int lo = 0, hi = S;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (srt[mid] <= v) lo = mid + 1; else hi = mid;
+                }
+                z_fine_out[(int64_t)r * n + lane + lo] = v;
+            }
+            for (int k = lane; k < S; k += WAVE) {               // rank of a coarse depth: new depths < it
+                const float zk = srt[k];
+                int lo = 0, hi = F;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (new_at(mid) < zk) lo = mid + 1; else hi = mid;
+                }
+                z_fine_out[(int64_t)r * n + k + lo] = zk;
+            }
+        } else {
+            bitonic_sort_lds(srt, npad, lane);
+            for (int k = lane; k < n; k += WAVE) z_fine_out[(int64_t)r * n + k] = srt[k];
+        }
     }
 }
 

@@ -260,6 +260,18 @@ def test_importance_resample(ops, dev, S, F, det):
     zn_o, _ = O.sample_pdf(O.midpoints(z), w[:, 1:-1], F, det=det, u=u)
     assert np.array_equal(N(zn), zn_o)
     assert np.array_equal(N(zf), np.sort(np.concatenate([z, zn_o], -1), -1))
+    # ties between the two runs and an UNSORTED coarse run (the reference sorts the concatenation whatever it is given):
+    # the fast rank-merge path must not be taken blindly
+    z2 = z.copy()
+    z2[1] = z2[1][::-1]                                               # descending
+    z2[2, min(5, S - 1)] = z2[2, min(5, S - 1) - 1]                   # duplicate depth
+    zf2, zn2 = ops.importance_resample(T(z2, dev), T(w, dev), F, None if det else T(u, dev), want_new=True)
+    assert np.array_equal(N(zf2), np.sort(np.concatenate([z2, N(zn2)], -1), -1))
+    z3 = z.copy()
+    z3[:, 1::2] = z3[:, 0::2][:, : z3[:, 1::2].shape[1]]              # every depth twice: ties inside and across runs
+    w3 = np.zeros_like(w)                                             # zero weights: new depths land on bin midpoints
+    zf3, zn3 = ops.importance_resample(T(z3, dev), T(w3, dev), F, None if det else T(u, dev), want_new=True)
+    assert np.array_equal(N(zf3), np.sort(np.concatenate([z3, N(zn3)], -1), -1))
 
 
 # --------------------------------------------------------------------------- a1
