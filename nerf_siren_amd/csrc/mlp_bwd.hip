@@ -394,7 +394,8 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
 //     two LDS buffers of 48 KiB; the staging of k-step i+1 (8 float4 per thread: load, split, three 8-byte LDS writes)
 //     is dealt out over the 16 accumulator units of k-step i, ~2 vector instructions per MFMA, hidden by the XDL pipe.
 //     LDS image of a k-step: [term 3][block 16 (8 dZ + 8 X)][row 32][16 points] bf16, the two 16-byte halves of a row
-//     swapped on rows with bit 2 set (rows r and r+4 would otherwise hit the same banks).
+//     swapped on rows where bit 2 and bit 3 differ: conflict-free ds_read_b128 whether the LDS serves 8 lanes x 32 banks or
+//     16 lanes x 64 banks per pass (a swap on bit 2 alone left 31 % conflict cycles, SQ_LDS_BANK_CONFLICT).
 // ---------------------------------------------------------------------------
 constexpr int DWF_KSTEP_BYTES = 3 * 16 * 1024;      // largest task: 8 + 8 blocks
 
@@ -432,7 +433,7 @@ __device__ __forceinline__ void dw_task_bf16x3(const DwTask &T, int chunk, const
     for (int j = 0; j < JB / 2; ++j) bsum[j] = 0.f;
     // LDS byte offset of this thread's 8 bytes inside (term 0, block 2j + (srow>>5)): row r = srow & 31
     const int r = srow & 31;
-    const unsigned woff = (unsigned)(((srow >> 5) * 1024) + r * 32 + (((c >> 1) ^ ((r >> 2) & 1)) * 16) + (c & 1) * 8);
+    const unsigned woff = (unsigned)(((srow >> 5) * 1024) + r * 32 + (((c >> 1) ^ (((r >> 2) ^ (r >> 3)) & 1)) * 16) + (c & 1) * 8);
     auto split_write = [&](int j, char *buf, bool real) {      // real = false: the redundant restaging past the end
         const f32x4 v = st[j];
         if (j < JB / 2) bsum[j] += real ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
@@ -467,7 +468,7 @@ __device__ __forceinline__ void dw_task_bf16x3(const DwTask &T, int chunk, const
     }
     __syncthreads();
     // fragment byte offset of this lane inside a (term, block) image
-    const unsigned foff = (unsigned)((lane & 31) * 32 + ((half ^ (((lane & 31) >> 2) & 1)) * 16));
+    const unsigned foff = (unsigned)((lane & 31) * 32 + ((half ^ ((((lane & 31) >> 2) ^ ((lane & 31) >> 3)) & 1)) * 16));
     auto kstep = [&](int64_t ks, const char *cur, char *nxt) __attribute__((always_inline)) {
         const int64_t k2 = (ks + 2 < k_hi) ? ks + 2 : k_hi - 1;     // past the end: restage the last one (branch-free)
         u32x4 a[JW][3], b[2][3];
