@@ -189,11 +189,25 @@ __global__ void eg3d_stratified_kernel(const float *__restrict__ start_t, const 
     }
 }
 
-// global min / max of the depths of one call (ray_marcher.py:50): one workgroup, deterministic
-__global__ void __launch_bounds__(1024) minmax_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
-    __shared__ float smin[16], smax[16];
+// global min / max of the depths of one call (ray_marcher.py:50).  min and max are exact and order-independent, so a
+// grid-wide reduction with atomics is still bit-reproducible; a single workgroup walking 2 M depths took 0.6 ms --
+// 39 % of the renderer's forward time at 16 384 rays.
+__global__ void minmax_init_kernel(float *__restrict__ out) {
+    out[0] = INFINITY;
+    out[1] = -INFINITY;
+}
+__device__ __forceinline__ void atomic_min_f32(float *addr, float v) {      // sign-aware integer ordering (no NaN)
+    if (v >= 0.f) atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
+    if (v >= 0.f) atomicMax(reinterpret_cast<int *>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
+}
+__global__ void __launch_bounds__(256) minmax_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+    __shared__ float smin[4], smax[4];
     float lo = INFINITY, hi = -INFINITY;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = x[i];
         lo = fminf(lo, v);
         hi = fmaxf(hi, v);
@@ -207,8 +221,8 @@ __global__ void __launch_bounds__(1024) minmax_kernel(const float *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fminf(lo, smin[w]); hi = fmaxf(hi, smax[w]); }
-        out[0] = lo;
-        out[1] = hi;
+        atomic_min_f32(out + 0, lo);
+        atomic_max_f32(out + 1, hi);
     }
 }
 
@@ -538,7 +552,10 @@ int nerfmi_eg3d_sample_stratified(const float *ray_start_t, const float *ray_end
 
 int nerfmi_eg3d_minmax(const float *x, int64_t n, float *minmax_out, nerfmi_stream_t stream) {
     NERFMI_REQUIRE(n >= 1 && x && minmax_out, "eg3d_minmax: bad arguments");
-    hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, minmax_out);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, minmax_out);
+    const int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, x, n,
+                       minmax_out);
     return check_launch("eg3d_minmax");
 }
 
