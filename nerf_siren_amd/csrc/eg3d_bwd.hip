@@ -289,7 +289,10 @@ triplane_backward_kernel(const float *__restrict__ planes, int N, int H, int W, 
 __global__ void __launch_bounds__(256)
 decoder_wgrad_kernel(const float *__restrict__ aux, int64_t aux_ld, int64_t total, int n_chunks,
                      float *__restrict__ partial) {
-    __shared__ float tile[AUX_F * 64];
+    // row pitch 65: the threads of a wave read the SAME point of 16 (or 32) different rows -- at a pitch of 64 floats that
+    // is one bank for all of them (a 16-way conflict; this kernel was 29 % of the renderer's training step)
+    constexpr int TP = 65;
+    __shared__ float tile[AUX_F * TP];
     const int t = threadIdx.x;
     const int64_t per = (total + n_chunks - 1) / n_chunks;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < total) ? lo + per : total;
@@ -300,16 +303,16 @@ decoder_wgrad_kernel(const float *__restrict__ aux, int64_t aux_ld, int64_t tota
         __syncthreads();
         for (int u = t; u < AUX_F * 64; u += 256) {
             const int f = u >> 6, pp = u & 63;
-            tile[u] = (p0 + pp < hi) ? aux[(int64_t)f * aux_ld + p0 + pp] : 0.f;
+            tile[f * TP + pp] = (p0 + pp < hi) ? aux[(int64_t)f * aux_ld + p0 + pp] : 0.f;
         }
         __syncthreads();
         for (int pp = 0; pp < 64; ++pp) {
-            const float dpre = tile[j0 * 64 + pp];
+            const float dpre = tile[j0 * TP + pp];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a0[k] = __builtin_fmaf(dpre, tile[(DEC_H + k0 + k) * 64 + pp], a0[k]);
-            a1 = __builtin_fmaf(tile[(2 * DEC_H + EC + k1) * 64 + pp], tile[(DEC_H + EC + j1) * 64 + pp], a1);
-            if (t < 64) ab0 += tile[t * 64 + pp];
-            if (t < 4) ab1 += tile[(2 * DEC_H + EC + t) * 64 + pp];
+            for (int k = 0; k < 8; ++k) a0[k] = __builtin_fmaf(dpre, tile[(DEC_H + k0 + k) * TP + pp], a0[k]);
+            a1 = __builtin_fmaf(tile[(2 * DEC_H + EC + k1) * TP + pp], tile[(DEC_H + EC + j1) * TP + pp], a1);
+            if (t < 64) ab0 += tile[t * TP + pp];
+            if (t < 4) ab1 += tile[(2 * DEC_H + EC + t) * TP + pp];
         }
     }
     float *out = partial + (int64_t)blockIdx.x * DEC_FLOATS;

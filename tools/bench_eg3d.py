@@ -39,6 +39,23 @@ def main():
             dt = timeit(lambda: ren(planes, dec, o, d, opts))
         print(json.dumps({"case": f"ImportanceRenderer fwd M={M} 64+64", "ms": dt * 1e3, "samples_per_s": M * 128 / dt,
                           "rays_per_s": M / dt}))
+    # training step of the renderer: forward + backward to the planes and the decoder (system.py:17-169 path)
+    for M in (1024, 4096):
+        o, d = synth.eg3d_rays(M, 3)
+        o, d = torch.from_numpy(o[None]).to(dev), torch.from_numpy(d[None]).to(dev)
+        pl = planes.clone().requires_grad_(True)
+        for p_ in dec.parameters():
+            p_.requires_grad_(True)
+
+        def train_step():
+            pl.grad = None
+            for p_ in dec.parameters():
+                p_.grad = None
+            out = ren(pl, dec, o, d, opts)
+            (out[0].square().mean() + out[1].mean()).backward()
+
+        dt = timeit(train_step, n=10)
+        print(json.dumps({"case": f"ImportanceRenderer fwd+bwd M={M} 64+64", "ms": dt * 1e3, "samples_per_s": M * 128 / dt}))
     g = np.linspace(-1.5, 1.5, 128, dtype=np.float32)
     pts = torch.from_numpy(np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(1, -1, 3)).to(dev)
     with torch.no_grad():
