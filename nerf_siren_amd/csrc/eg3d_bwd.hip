@@ -286,41 +286,68 @@ triplane_backward_kernel(const float *__restrict__ planes, int N, int H, int W, 
 }
 
 // decoder parameter gradients: chunk of points -> partial slab [DEC_FLOATS]
+// A 64-point tile of the per-point intermediates ([field][point] in memory) is transposed into LDS as [point][field];
+// the four waves take every fourth point, and a lane owns a 4 x 8 block of dW0 (rows 4jb.., columns 8kb..), one row of
+// dW1^T and one entry of db0: per point it reads 3 + 2 sixteen-byte fragments for 38 FMAs.  (The first version read one
+// LDS dword per FMA at a 64-float row pitch -- a 16-way bank conflict -- and was 29 % of the renderer's training step.)
 __global__ void __launch_bounds__(256)
 decoder_wgrad_kernel(const float *__restrict__ aux, int64_t aux_ld, int64_t total, int n_chunks,
                      float *__restrict__ partial) {
-    // row pitch 65: the threads of a wave read the SAME point of 16 (or 32) different rows -- at a pitch of 64 floats that
-    // is one bank for all of them (a 16-way conflict; this kernel was 29 % of the renderer's training step)
-    constexpr int TP = 65;
-    __shared__ float tile[AUX_F * TP];
-    const int t = threadIdx.x;
+    constexpr int PITCH = AUX_F;                       // 164 floats: 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) float tile[64 * PITCH];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int t = threadIdx.x, g = t >> 6, l = t & 63;
     const int64_t per = (total + n_chunks - 1) / n_chunks;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < total) ? lo + per : total;
-    // thread t: dW0[j][8k0..8k0+7] with j = t>>2, k0 = t&3 ; dW1[t>>6][t&63] ; db0[t] (t<64) ; db1[t] (t<4)
-    const int j0 = t >> 2, k0 = (t & 3) * 8, j1 = t & 63, k1 = t >> 6;
-    float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = 0.f, ab0 = 0.f, ab1 = 0.f;
+    const int jb = l >> 2, kb = l & 3;
+    float a0[4][8], a1[4] = {0.f, 0.f, 0.f, 0.f}, ab0 = 0.f, ab1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a0[i][k] = 0.f;
     for (int64_t p0 = lo; p0 < hi; p0 += 64) {
         __syncthreads();
         for (int u = t; u < AUX_F * 64; u += 256) {
             const int f = u >> 6, pp = u & 63;
-            tile[f * TP + pp] = (p0 + pp < hi) ? aux[(int64_t)f * aux_ld + p0 + pp] : 0.f;
+            tile[pp * PITCH + f] = (p0 + pp < hi) ? aux[(int64_t)f * aux_ld + p0 + pp] : 0.f;
         }
         __syncthreads();
-        for (int pp = 0; pp < 64; ++pp) {
-            const float dpre = tile[j0 * TP + pp];
+#pragma unroll 4
+        for (int pp = g; pp < 64; pp += 4) {
+            const float *row = tile + pp * PITCH;         // [d_pre(64) | m(32) | h(64) | d_x(4)]
+            const f4 dp = *reinterpret_cast<const f4 *>(row + 4 * jb);
+            const f4 m0 = *reinterpret_cast<const f4 *>(row + DEC_H + 8 * kb), m1 = *reinterpret_cast<const f4 *>(row + DEC_H + 8 * kb + 4);
+            const f4 dx = *reinterpret_cast<const f4 *>(row + 2 * DEC_H + EC);
+            const float hh = row[DEC_H + EC + l];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a0[k] = __builtin_fmaf(dpre, tile[(DEC_H + k0 + k) * TP + pp], a0[k]);
-            a1 = __builtin_fmaf(tile[(2 * DEC_H + EC + k1) * TP + pp], tile[(DEC_H + EC + j1) * TP + pp], a1);
-            if (t < 64) ab0 += tile[t * TP + pp];
-            if (t < 4) ab1 += tile[(2 * DEC_H + EC + t) * TP + pp];
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a0[i][k] = __builtin_fmaf(dp[i], m0[k], a0[i][k]);
+                    a0[i][4 + k] = __builtin_fmaf(dp[i], m1[k], a0[i][4 + k]);
+                }
+                a1[i] = __builtin_fmaf(dx[i], hh, a1[i]);
+            }
+            ab0 += row[l];
+            if (l < 4) ab1 += row[2 * DEC_H + EC + l];
         }
     }
-    float *out = partial + (int64_t)blockIdx.x * DEC_FLOATS;
+    // sum the four waves' partial blocks through LDS, then one slab per chunk
+    __syncthreads();
+    float *red = tile;                                    // [g][DEC_FLOATS]
+    float *mine = red + g * DEC_FLOATS;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) out[j0 * EC + k0 + k] = a0[k];
-    if (t < 64) out[DEC_H * EC + t] = ab0;
-    out[DEC_H * EC + DEC_H + k1 * DEC_H + j1] = a1;
-    if (t < 4) out[DEC_H * EC + DEC_H + 4 * DEC_H + t] = ab1;
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mine[(4 * jb + i) * EC + 8 * kb + k] = a0[i][k];
+        mine[DEC_H * EC + DEC_H + i * DEC_H + l] = a1[i];
+    }
+    mine[DEC_H * EC + l] = ab0;
+    if (l < 4) mine[DEC_H * EC + DEC_H + 4 * DEC_H + l] = ab1;
+    __syncthreads();
+    float *out = partial + (int64_t)blockIdx.x * DEC_FLOATS;
+    for (int i = t; i < DEC_FLOATS; i += 256)
+        out[i] = (red[i] + red[DEC_FLOATS + i]) + (red[2 * DEC_FLOATS + i] + red[3 * DEC_FLOATS + i]);
 }
 
 // sum the chunk slabs, apply FullyConnectedLayer's gains (w_eff = w*gain, b_eff = b*lr_mul)
