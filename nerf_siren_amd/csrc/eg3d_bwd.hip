@@ -356,8 +356,17 @@ __global__ void decoder_wgrad_reduce_kernel(const float *__restrict__ partial, i
                                             float *__restrict__ g_w1, float *__restrict__ g_b1) {
     const float gain0 = (float)((double)lr_mul / sqrt((double)EC)), gain1 = (float)((double)lr_mul / sqrt((double)DEC_H));
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < DEC_FLOATS; i += gridDim.x * blockDim.x) {
+        // fixed order (bit-reproducible), eight slab loads in flight at a time
         float s = 0.f;
-        for (int c = 0; c < n_chunks; ++c) s += partial[(int64_t)c * DEC_FLOATS + i];
+        int c = 0;
+        for (; c + 8 <= n_chunks; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(c + u) * DEC_FLOATS + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c < n_chunks; ++c) s += partial[(int64_t)c * DEC_FLOATS + i];
         float *dst;
         float g;
         if (i < DEC_H * EC) { dst = g_w0 + i; g = gain0; }
@@ -385,7 +394,7 @@ static inline int grid_for(int64_t total, int block) {
     int64_t g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
 }
-constexpr int WGRAD_CHUNKS = 128;
+constexpr int WGRAD_CHUNKS = 768;   // three workgroups per CU (42 KB of LDS each): one loads its tile while another computes
 
 }  // namespace nerfmi
 
