@@ -355,18 +355,28 @@ __global__ void decoder_wgrad_reduce_kernel(const float *__restrict__ partial, i
                                             float *__restrict__ g_w0, float *__restrict__ g_b0,
                                             float *__restrict__ g_w1, float *__restrict__ g_b1) {
     const float gain0 = (float)((double)lr_mul / sqrt((double)EC)), gain1 = (float)((double)lr_mul / sqrt((double)DEC_H));
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < DEC_FLOATS; i += gridDim.x * blockDim.x) {
-        // fixed order (bit-reproducible), eight slab loads in flight at a time
-        float s = 0.f;
-        int c = 0;
-        for (; c + 8 <= n_chunks; c += 8) {
+    // one workgroup per 64 entries: wave w sums chunks [w*q, (w+1)*q) with eight slab loads in flight, then the four
+    // partial sums meet in LDS in a fixed order (bit-reproducible run to run)
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const int q = (n_chunks + 3) / 4, c0 = w * q, c1 = min(n_chunks, c0 + q);
+    float s = 0.f;
+    if (i < DEC_FLOATS) {
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(c + u) * DEC_FLOATS + i];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; c < n_chunks; ++c) s += partial[(int64_t)c * DEC_FLOATS + i];
+        for (; c < c1; ++c) s += partial[(int64_t)c * DEC_FLOATS + i];
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < DEC_FLOATS) {
+        s = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
         float *dst;
         float g;
         if (i < DEC_H * EC) { dst = g_w0 + i; g = gain0; }
@@ -462,7 +472,7 @@ int nerfmi_eg3d_decoder_wgrad(const float *aux, int64_t n_points, float lr_multi
     const int64_t aux_ld = (n_points + 63) / 64 * 64;
     hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(WGRAD_CHUNKS), dim3(256), 0, (hipStream_t)stream, aux, aux_ld, n_points,
                        WGRAD_CHUNKS, partial);
-    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3(10), dim3(256), 0, (hipStream_t)stream, partial, WGRAD_CHUNKS,
+    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3((DEC_FLOATS + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, WGRAD_CHUNKS,
                        lr_multiplier, accumulate, g_w0, g_b0, g_w1, g_b1);
     return check_launch("eg3d_decoder_wgrad");
 }
