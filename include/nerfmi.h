@@ -120,6 +120,24 @@ int nerfmi_siren_forward_rays(const float *packed, const float *rays, const floa
                               const float *phase_shifts, int n_rays, int n_per_ray, int64_t rays_per_cond,
                               int sigma_only, float *out, nerfmi_stream_t stream);
 
+/* Training path of the FiLM-SIREN field (autograd of models/nerf.py:142-151, :201-216 w.r.t. the 22 parameters; the
+ * inputs and the conditioning rows carry no gradient here).  The *_train forwards also write `saved`
+ * (nerfmi_siren_saved_floats(n_points) floats: per 32-point tile the layer inputs and one sign bit of cos per unit);
+ * nerfmi_siren_backward turns grad_out (n_points,4) = [d rgb, d sigma] into the 22 gradients (written, not
+ * accumulated; bit-reproducible: fixed-order slab reduction, no float atomics).  grad_params: HOST array of 22 DEVICE
+ * pointers in state_dict order; workspace: nerfmi_siren_backward_workspace_floats(n_points) floats. */
+size_t nerfmi_siren_saved_floats(int64_t n_points);
+size_t nerfmi_siren_backward_workspace_floats(int64_t n_points);
+int nerfmi_siren_forward_rays_train(const float *packed, const float *rays, const float *z, const float *frequencies,
+                                    const float *phase_shifts, int n_rays, int n_per_ray, int64_t rays_per_cond,
+                                    float *out, float *saved, nerfmi_stream_t stream);
+int nerfmi_siren_forward_points_train(const float *packed, const float *points, const float *ray_directions,
+                                      const float *frequencies, const float *phase_shifts, int64_t n_points,
+                                      int64_t points_per_cond, float *out, float *saved, nerfmi_stream_t stream);
+int nerfmi_siren_backward(const float *packed, const float *saved, const float *grad_out, const float *frequencies,
+                          int64_t n_points, int64_t points_per_cond, float *const *grad_params, float *workspace,
+                          nerfmi_stream_t stream);
+
 /* OPT-IN split-bf16 math for the FiLM-SIREN field (see nerfmi_nerf_forward_rays_fast): `fast`
  * (nerfmi_siren_fast_bytes() bytes) is derived from the SIREN `packed` blob by nerfmi_siren_pack_fast. */
 size_t nerfmi_siren_fast_bytes(void);

@@ -8,28 +8,11 @@
 // per 32-unit block, placed between the next block's MFMAs (layer_mfma), so the
 // 2304 sines per point execute in the shadow of the matrix pipe.
 #include "bf16x3_core.h"
+#include "siren_core.h"
 
 namespace nerfmi {
 
-// packed SIREN image (floats)
-constexpr int SOFF_L1 = 0;                          // 8 jb x 1 kb   (3 valid input columns)
-constexpr int SSZ_L1 = 8 * 1 * 1024;
-constexpr int SOFF_L2 = SOFF_L1 + SSZ_L1;           // 7 hidden layers, 8 x 8 each
-constexpr int SOFF_COLOR = SOFF_L2 + 7 * SZ_HID;    // 8 jb x 9 kb   ([dir 3 | hidden 256], nerf.py:213)
-constexpr int SSZ_COLOR = 8 * 9 * 1024;
-constexpr int SOFF_BIAS = SOFF_COLOR + SSZ_COLOR;   // 9 x 256 (network.0..7, color_layer_sine)
-constexpr int SOFF_W_SIGMA = SOFF_BIAS + 9 * 256;   // 256
-constexpr int SOFF_B_SIGMA = SOFF_W_SIGMA + 256;    // 1 (+3)
-constexpr int SOFF_W_RGB = SOFF_B_SIGMA + 4;        // 3 x 256
-constexpr int SOFF_B_RGB = SOFF_W_RGB + 768;        // 3 (+1)
-// readable tail: the weight stream prefetches two stages past the color layer (mlp_core.h layer_mfma_lds)
-constexpr int SIREN_PACKED_FLOATS = SOFF_BIAS + (SOFF_B_RGB + 4 - SOFF_BIAS > 2 * GS * 256 ? SOFF_B_RGB + 4 - SOFF_BIAS : 2 * GS * 256);
-constexpr int SIREN_N_PARAMS = 22;  // network.{0..7}.layer.{weight,bias}, final_layer.*, color_layer_sine.layer.*, color_layer_linear.0.*
-
-struct SirenParamPtrs {
-    const float *p[SIREN_N_PARAMS];
-};
-
+// state_dict tensors -> fragment-order images (siren_core.h; operand maps in mlp_layout.h)
 __global__ void siren_pack_kernel(SirenParamPtrs P, float *__restrict__ packed) {
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < SIREN_PACKED_FLOATS; idx += gridDim.x * blockDim.x) {
         float v = 0.f;
@@ -54,96 +37,18 @@ __global__ void siren_pack_kernel(SirenParamPtrs P, float *__restrict__ packed) 
         } else if (idx < SOFF_B_SIGMA) v = P.p[16][idx - SOFF_W_SIGMA];
         else if (idx < SOFF_W_RGB) v = (idx == SOFF_B_SIGMA) ? P.p[17][0] : 0.f;
         else if (idx < SOFF_B_RGB) v = P.p[20][idx - SOFF_W_RGB];
-        else v = (idx - SOFF_B_RGB < 3) ? P.p[21][idx - SOFF_B_RGB] : 0.f;
-        packed[idx] = v;
-    }
-}
-
-template <bool FROM_RAYS, bool SIGMA_ONLY>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__ rays, const float *__restrict__ z,
-                     const float *__restrict__ pts, const float *__restrict__ dirs, const float *__restrict__ freq,
-                     const float *__restrict__ phase, int64_t n_points, int n_per_ray, int64_t points_per_cond,
-                     float *__restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int half = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t p0 = wave * 32;       // no early exit: the workgroup's waves share barriers (layer_mfma_lds)
-    const int64_t praw = p0 + (lane & 31);
-    const bool ok = praw < n_points;
-    const int64_t p = ok ? praw : n_points - 1;
-
-    float x[3], d[3];
-    if (FROM_RAYS) {
-        const float *rr = rays + (p / n_per_ray) * 8;
-        const float zz = z[p];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            x[c] = __fadd_rn(rr[c], __fmul_rn(rr[3 + c], zz));      // rendering.py:224-225
-            d[c] = rr[3 + c];
+        else if (idx < SOFF_B_RGB + 4) v = (idx - SOFF_B_RGB < 3) ? P.p[21][idx - SOFF_B_RGB] : 0.f;
+        else if (idx >= SOFF_TRANS && idx < SOFF_T7 + 7 * SZ_HID) {
+            // transposed images, backward order: colour layer (hidden columns), network.7 .. network.1
+            const int ti = (idx - SOFF_TRANS) / SZ_HID;                  // 0 = colour, 1 + k = network.(7 - k)
+            const int rel = (idx - SOFF_TRANS) % SZ_HID;
+            const int t = rel & 3, lane = (rel >> 2) & 63, g = rel >> 8;
+            const int q = g & 3, jb = (g >> 2) % 8, kbo = (g >> 2) / 8;
+            const int row = 32 * jb + 8 * q + 4 * (lane >> 5) + t;       // W row (output unit)
+            const int col = 32 * kbo + (lane & 31);                      // hidden input unit
+            v = (ti == 0) ? P.p[18][row * 259 + 3 + col] : P.p[2 * (8 - ti)][row * 256 + col];
         }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { x[c] = pts[p * 3 + c]; d[c] = dirs ? dirs[p * 3 + c] : 0.f; }
-    }
-    const float warp = 2.0f / 51.0f;                                 // UniformBoxWarp(51), nerf.py:134-140, :193
-    f32x16 e[1], de[1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int c = 8 * (r >> 2) + 4 * half + (r & 3);
-        e[0][r] = (c < 3) ? __fmul_rn(x[c < 3 ? c : 0], warp) : 0.f;
-        de[0][r] = (c < 3) ? d[c < 3 ? c : 0] : 0.f;
-    }
-    // this lane's conditioning row (frequencies, phase_shifts are (n_cond, 9*256))
-    const float *fq = freq + (p / points_per_cond) * 2304 + 4 * half;
-    const float *ph = phase + (p / points_per_cond) * 2304 + 4 * half;
-    auto film_epi = [&](int layer) {
-        return [fq, ph, layer](int jb, int q, f32x4 c, int) {
-            const f32x4 f = ldg4(fq + 256 * layer + 32 * jb + 8 * q);
-            const f32x4 s = ldg4(ph + 256 * layer + 32 * jb + 8 * q);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float fr = __fadd_rn(__fmul_rn(f[t], 15.0f), 30.0f);          // nerf.py:202
-                c[t] = sin_cw(__fadd_rn(__fmul_rn(fr, c[t]), s[t]));                  // nerf.py:151
-            }
-            return c;
-        };
-    };
-    auto no_pre = [](int) { return 0; };
-    __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
-    const int wid = threadIdx.x >> 6;
-    const float *bias = packed + SOFF_BIAS + 4 * half;
-    f32x16 hA[8], hB[8];                   // alternate: a layer reads one, its epilogue writes the other (no copies)
-    WeightStage ws;
-    // ring phases: network.0 is 2 stages, every hidden layer 16, so the hidden and color layers start at phase 2
-    layer_mfma_lds<1, 0, 8, 0, true>(packed + SOFF_L1, bias, e, nullptr, hA, no_pre, film_epi(0), wlds, ws, wid, lane);
-    auto hidden = [&](int l, const f32x16 *in, f32x16 *out_h) __attribute__((always_inline)) {
-        layer_mfma_lds<8, 0, 8, 2, false>(packed + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, in, nullptr, out_h, no_pre,
-                                          film_epi(l), wlds, ws, wid, lane);
-    };
-    hidden(1, hA, hB);
-    hidden(2, hB, hA);
-    hidden(3, hA, hB);
-    hidden(4, hB, hA);
-    hidden(5, hA, hB);
-    hidden(6, hB, hA);
-    hidden(7, hA, hB);
-    const float sigma = dot_blocks<8>(hB, packed + SOFF_W_SIGMA + 4 * half) + packed[SOFF_B_SIGMA];   // nerf.py:212
-    if (SIGMA_ONLY) {
-        if (ok && half == 0) out[p] = sigma;
-        return;
-    }
-    layer_mfma_lds<1, 8, 8, 2, false>(packed + SOFF_COLOR, bias + 256 * 8, de, hB, hA, no_pre, film_epi(8), wlds, ws, wid, lane);            // nerf.py:213
-    float rgb[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float pre = dot_blocks<8>(hA, packed + SOFF_W_RGB + 256 * c + 4 * half) + packed[SOFF_B_RGB + c];
-        rgb[c] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-pre)));                                         // nerf.py:214
-    }
-    if (ok && half == 0) {
-        float4 o;
-        o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2]; o.w = sigma;
-        reinterpret_cast<float4 *>(out)[p] = o;
+        packed[idx] = v;
     }
 }
 
@@ -282,11 +187,11 @@ int nerfmi_siren_forward_points(const float *packed, const float *points, const 
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (sigma_only)
-        hipLaunchKernelGGL((siren_forward_kernel<false, true>), grid, block, 0, st, packed, nullptr, nullptr, points,
-                           ray_directions, frequencies, phase_shifts, n_points, 1, points_per_cond, out);
+        hipLaunchKernelGGL((siren_forward_kernel<false, true, false>), grid, block, 0, st, packed, nullptr, nullptr, points,
+                           ray_directions, frequencies, phase_shifts, n_points, 1, points_per_cond, out, nullptr, (int64_t)0);
     else
-        hipLaunchKernelGGL((siren_forward_kernel<false, false>), grid, block, 0, st, packed, nullptr, nullptr, points,
-                           ray_directions, frequencies, phase_shifts, n_points, 1, points_per_cond, out);
+        hipLaunchKernelGGL((siren_forward_kernel<false, false, false>), grid, block, 0, st, packed, nullptr, nullptr, points,
+                           ray_directions, frequencies, phase_shifts, n_points, 1, points_per_cond, out, nullptr, (int64_t)0);
     return check_launch("siren_forward_points");
 }
 
@@ -301,11 +206,11 @@ int nerfmi_siren_forward_rays(const float *packed, const float *rays, const floa
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (sigma_only)
-        hipLaunchKernelGGL((siren_forward_kernel<true, true>), grid, block, 0, st, packed, rays, z, nullptr, nullptr,
-                           frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out);
+        hipLaunchKernelGGL((siren_forward_kernel<true, true, false>), grid, block, 0, st, packed, rays, z, nullptr, nullptr,
+                           frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out, nullptr, (int64_t)0);
     else
-        hipLaunchKernelGGL((siren_forward_kernel<true, false>), grid, block, 0, st, packed, rays, z, nullptr, nullptr,
-                           frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out);
+        hipLaunchKernelGGL((siren_forward_kernel<true, false, false>), grid, block, 0, st, packed, rays, z, nullptr, nullptr,
+                           frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out, nullptr, (int64_t)0);
     return check_launch("siren_forward_rays");
 }
 

@@ -69,6 +69,13 @@ class NeRF(nn.Module):
         """Called by writers that change parameter memory without going through torch (training.FusedAdam)."""
         self._epoch = getattr(self, "_epoch", 0) + 1
 
+    grad_numel = ops.PARAM_NUMEL
+
+    @staticmethod
+    def grad_views(flat):
+        """The 24 gradient tensors as views of one flat buffer, in param_list() order."""
+        return ops.flat_views(flat)
+
     def packed(self):
         """Fragment-order weight blob (csrc/mlp_layout.h), re-packed when any
         parameter changed (optimizer steps bump tensor._version)."""
@@ -166,9 +173,20 @@ class SemanticNeRF(nn.Module):
         sd = dict(self.named_parameters())
         return [sd[k] for k in ops.SIREN_PARAM_ORDER]
 
+    def mark_parameters_changed(self):
+        """Called by writers that change parameter memory without going through torch (training.FusedAdam)."""
+        self._epoch = getattr(self, "_epoch", 0) + 1
+
+    grad_numel = ops.SIREN_PARAM_NUMEL
+
+    @staticmethod
+    def grad_views(flat):
+        """The 22 gradient tensors as views of one flat buffer, in param_list() order."""
+        return ops.siren_flat_views(flat)
+
     def packed(self):
         ps = self.param_list()
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        key = (getattr(self, "_epoch", 0),) + tuple((p.data_ptr(), p._version) for p in ps)
         if self._packed is None or key != self._packed_key or self._packed.device != ps[0].device:
             self._packed = ops.siren_pack(ps)
             self._packed_key = key
@@ -188,14 +206,19 @@ class SemanticNeRF(nn.Module):
                              "use forward_with_frequencies_phase_shifts")
 
     def forward_with_frequencies_phase_shifts(self, input, frequencies, phase_shifts, ray_directions, **kwargs):
-        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
-            if input.requires_grad:
-                raise NotImplementedError("gradients w.r.t. SIREN inputs are not implemented")
+        """nerf.py:201-216.  Differentiable w.r.t. the 22 parameters; gradients w.r.t. the points, the directions and
+        the conditioning rows (which the reference would get from its never-defined mapping network) are not provided."""
         bz, npts = input.shape[0], input.shape[1]
-        out = ops.siren_forward_points(self.packed(), input.reshape(-1, 3).contiguous(),
-                                       ray_directions.reshape(-1, 3).contiguous(),
-                                       frequencies.reshape(bz, -1).contiguous(), phase_shifts.reshape(bz, -1).contiguous(),
-                                       npts)
+        pts = input.reshape(-1, 3).contiguous()
+        dirs = ray_directions.reshape(-1, 3).contiguous()
+        freq, phase = frequencies.reshape(bz, -1).contiguous(), phase_shifts.reshape(bz, -1).contiguous()
+        if torch.is_grad_enabled():
+            if any(t.requires_grad for t in (input, frequencies, phase_shifts, ray_directions)):
+                raise NotImplementedError("gradients w.r.t. SIREN inputs / frequencies / phase_shifts are not implemented")
+            if any(p.requires_grad for p in self.parameters()):
+                from .rendering import SirenPoints
+                return SirenPoints.apply(self, pts, dirs, freq, phase, npts, *self.param_list()).view(bz, npts, 4)
+        out = ops.siren_forward_points(self.packed(), pts, dirs, freq, phase, npts)
         return out.view(bz, npts, 4)
 
 
@@ -212,6 +235,19 @@ class SirenField(nn.Module):
                                         requires_grad=False)
         self.phase_shifts = nn.Parameter(torch.zeros(1, h) if phase_shifts is None else phase_shifts.reshape(1, h).clone(),
                                          requires_grad=False)
+
+    # the training protocol of rendering.FieldRender / training.FusedAdam / parallel.FlatGradAllReduce
+    def param_list(self):
+        return self.model.param_list()
+
+    def mark_parameters_changed(self):
+        self.model.mark_parameters_changed()
+
+    grad_numel = ops.SIREN_PARAM_NUMEL
+
+    @staticmethod
+    def grad_views(flat):
+        return ops.siren_flat_views(flat)
 
     def field_rays(self, rays, z, sigma_only=False):
         from .rendering import get_math

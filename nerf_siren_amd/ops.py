@@ -36,6 +36,32 @@ def _req(t: torch.Tensor, name: str, shape=None, dtype=torch.float32):
     return t
 
 
+# Profiling hook: bench.py brackets the field-MLP launches with HIP events on the launch stream.  hook(name, n_per_ray)
+# returns None or an object with .done(), called right after the launch was enqueued (same stream).
+_PROFILE_HOOK = None
+
+
+def set_profile_hook(hook):
+    """hook(name: str, n_per_ray: int) -> None | object with .done(); None removes the hook."""
+    global _PROFILE_HOOK
+    _PROFILE_HOOK = hook
+
+
+class _Span:
+    __slots__ = ("h",)
+
+    def __init__(self, name, n_per_ray):
+        self.h = _PROFILE_HOOK(name, n_per_ray) if _PROFILE_HOOK is not None else None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.h is not None:
+            self.h.done()
+        return False
+
+
 def version() -> int:
     return _lib.lib().nerfmi_version()
 
@@ -117,8 +143,9 @@ def nerf_forward_rays(packed, rays, z, sigma_only=False, save=False):
     saved = None
     if save:
         saved = torch.empty(nerf_saved_floats(n * p), device=rays.device, dtype=torch.float32)
-    check(_lib.lib().nerfmi_nerf_forward_rays(ptr(packed), ptr(rays), ptr(z), n, p, int(bool(sigma_only)), ptr(out),
-                                              ptr(saved), _stream(rays)), "nerf_forward_rays")
+    with _Span("nerf_forward_rays", p):
+        check(_lib.lib().nerfmi_nerf_forward_rays(ptr(packed), ptr(rays), ptr(z), n, p, int(bool(sigma_only)), ptr(out),
+                                                  ptr(saved), _stream(rays)), "nerf_forward_rays")
     return (out, saved) if save else out
 
 
@@ -135,9 +162,10 @@ def nerf_forward_rays_fast(packed, fast, rays, z, sigma_only=False, save=False):
     n, p = z.shape
     out = torch.empty((n * p, 1 if sigma_only else 4), device=rays.device, dtype=torch.float32)
     saved = torch.empty(nerf_saved_floats(n * p), device=rays.device, dtype=torch.float32) if save else None
-    check(_lib.lib().nerfmi_nerf_forward_rays_fast(ptr(packed), ptr(fast), ptr(rays), ptr(z), n, p,
-                                                   int(bool(sigma_only)), ptr(out), ptr(saved), _stream(rays)),
-          "nerf_forward_rays_fast")
+    with _Span("nerf_forward_rays_fast", p):
+        check(_lib.lib().nerfmi_nerf_forward_rays_fast(ptr(packed), ptr(fast), ptr(rays), ptr(z), n, p,
+                                                       int(bool(sigma_only)), ptr(out), ptr(saved), _stream(rays)),
+              "nerf_forward_rays_fast")
     return (out, saved) if save else out
 
 
@@ -212,10 +240,79 @@ def siren_forward_rays(packed, rays, z, freq, phase, rays_per_cond, sigma_only=F
     if freq.shape[0] * rays_per_cond < n:
         raise ValueError("frequencies has too few rows for the rays")
     out = torch.empty((n * p, 1 if sigma_only else 4), device=rays.device, dtype=torch.float32)
-    check(_lib.lib().nerfmi_siren_forward_rays(ptr(packed), ptr(rays), ptr(z), ptr(freq), ptr(phase), n, p,
-                                               int(rays_per_cond), int(bool(sigma_only)), ptr(out), _stream(rays)),
-          "siren_forward_rays")
+    with _Span("siren_forward_rays", p):
+        check(_lib.lib().nerfmi_siren_forward_rays(ptr(packed), ptr(rays), ptr(z), ptr(freq), ptr(phase), n, p,
+                                                   int(rays_per_cond), int(bool(sigma_only)), ptr(out), _stream(rays)),
+              "siren_forward_rays")
     return out
+
+
+SIREN_PARAM_SIZES = [int(torch.Size(s).numel()) for s in SIREN_PARAM_SHAPES]
+SIREN_PARAM_NUMEL = sum(SIREN_PARAM_SIZES)          # 529 156
+
+
+def siren_flat_views(flat):
+    """The 22 parameter-shaped views of one contiguous buffer (SIREN_PARAM_ORDER), cf. flat_views."""
+    out, off = [], 0
+    for shape, n in zip(SIREN_PARAM_SHAPES, SIREN_PARAM_SIZES):
+        out.append(flat[off:off + n].view(shape))
+        off += n
+    return out
+
+
+def _siren_cond(freq, phase, n_groups, per_cond):
+    freq = _req(freq, "frequencies", (None, 2304))
+    phase = _req(phase, "phase_shifts", (freq.shape[0], 2304))
+    if per_cond < 1 or freq.shape[0] * per_cond < n_groups:
+        raise ValueError("frequencies has too few rows")
+    return freq, phase
+
+
+def siren_forward_rays_train(packed, rays, z, freq, phase, rays_per_cond):
+    """Training forward of the FiLM-SIREN field behind the ray sampler -> (out (n*p,4), saved)."""
+    rays = _req(rays, "rays", (None, 8))
+    z = _req(z, "z", (rays.shape[0], None))
+    n, p = z.shape
+    freq, phase = _siren_cond(freq, phase, n, int(rays_per_cond))
+    packed = _req(packed, "packed", (_lib.lib().nerfmi_siren_packed_floats(),))
+    out = torch.empty((n * p, 4), device=rays.device, dtype=torch.float32)
+    saved = torch.empty(_lib.lib().nerfmi_siren_saved_floats(n * p), device=rays.device, dtype=torch.float32)
+    with _Span("siren_forward_rays_train", p):
+        check(_lib.lib().nerfmi_siren_forward_rays_train(ptr(packed), ptr(rays), ptr(z), ptr(freq), ptr(phase), n, p,
+                                                         int(rays_per_cond), ptr(out), ptr(saved), _stream(rays)),
+              "siren_forward_rays_train")
+    return out, saved
+
+
+def siren_forward_points_train(packed, points, dirs, freq, phase, points_per_cond):
+    points = _req(points, "points", (None, 3))
+    n = points.shape[0]
+    dirs = _req(dirs, "ray_directions", (n, 3))
+    freq, phase = _siren_cond(freq, phase, n, int(points_per_cond))
+    packed = _req(packed, "packed", (_lib.lib().nerfmi_siren_packed_floats(),))
+    out = torch.empty((n, 4), device=points.device, dtype=torch.float32)
+    saved = torch.empty(_lib.lib().nerfmi_siren_saved_floats(n), device=points.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_siren_forward_points_train(ptr(packed), ptr(points), ptr(dirs), ptr(freq), ptr(phase), n,
+                                                       int(points_per_cond), ptr(out), ptr(saved), _stream(points)),
+          "siren_forward_points_train")
+    return out, saved
+
+
+def siren_backward(packed, saved, grad_out, freq, points_per_cond, grads=None):
+    """-> list of 22 gradient tensors (SIREN_PARAM_ORDER), written not accumulated."""
+    grad_out = _req(grad_out, "grad_out", (None, 4))
+    n = grad_out.shape[0]
+    freq = _req(freq, "frequencies", (None, 2304))
+    if points_per_cond < 1 or freq.shape[0] * points_per_cond < n:
+        raise ValueError("frequencies has too few rows")
+    packed = _req(packed, "packed", (_lib.lib().nerfmi_siren_packed_floats(),))
+    saved = _req(saved, "saved", (_lib.lib().nerfmi_siren_saved_floats(n),))
+    if grads is None:
+        grads = siren_flat_views(torch.empty(SIREN_PARAM_NUMEL, device=grad_out.device, dtype=torch.float32))
+    ws = torch.empty(_lib.lib().nerfmi_siren_backward_workspace_floats(n), device=grad_out.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_siren_backward(ptr(packed), ptr(saved), ptr(grad_out), ptr(freq), n, int(points_per_cond),
+                                           _ptr_array(grads), ptr(ws), _stream(grad_out)), "siren_backward")
+    return grads
 
 
 def siren_pack_fast(packed):
@@ -233,9 +330,10 @@ def siren_forward_rays_fast(packed, fast, rays, z, freq, phase, rays_per_cond, s
     if freq.shape[0] * rays_per_cond < n:
         raise ValueError("frequencies has too few rows for the rays")
     out = torch.empty((n * p, 1 if sigma_only else 4), device=rays.device, dtype=torch.float32)
-    check(_lib.lib().nerfmi_siren_forward_rays_fast(ptr(packed), ptr(fast), ptr(rays), ptr(z), ptr(freq), ptr(phase), n, p,
-                                                    int(rays_per_cond), int(bool(sigma_only)), ptr(out), _stream(rays)),
-          "siren_forward_rays_fast")
+    with _Span("siren_forward_rays_fast", p):
+        check(_lib.lib().nerfmi_siren_forward_rays_fast(ptr(packed), ptr(fast), ptr(rays), ptr(z), ptr(freq), ptr(phase), n, p,
+                                                        int(rays_per_cond), int(bool(sigma_only)), ptr(out), _stream(rays)),
+              "siren_forward_rays_fast")
     return out
 
 

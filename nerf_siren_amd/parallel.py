@@ -34,32 +34,51 @@ def flat_grad_alias(params):
 class FlatGradAllReduce:
     """all-reduce(mean) of the models' gradients with as few collectives as storage allows.
 
-    The HIP backward writes a model's 24 gradients into one contiguous buffer (ops.flat_views), so
-    after loss.backward() every p.grad of a NeRF is a view of the same base tensor: that base is
-    all-reduced directly (one collective per model, no copies).  Gradients that do not share a base
-    (foreign modules, accumulated grads) are flattened into a scratch buffer instead.
+    The HIP backward writes a model's gradients into one contiguous buffer (model.grad_views), so after
+    loss.backward() every p.grad of a model is a view of the same base tensor: that base is all-reduced directly (no
+    copies).  All models share ONE joint buffer (model i owns slice i), so without overlap the step's exchange is a
+    single collective.  Gradients that do not share a base (foreign modules, accumulated grads) are flattened into a
+    scratch buffer instead.
+
+    overlap=True (world > 1): the two field passes of render_rays are independent in the backward (rendering.py:243-245
+    .detach()), and autograd runs the fine pass first.  As soon as a model's backward has ENQUEUED its gradient kernels,
+    its slice is all-reduced asynchronously (RCCL's own stream waits for the compute stream at that point), so the fine
+    model's collective runs under the coarse model's backward; all_reduce() then only waits.  This needs every model to be
+    applied at most once per backward pass (a second application is refused loudly: its contribution would be added to
+    a buffer that is already on the wire).
     """
 
-    def __init__(self, models, world_size: int | None = None, group=None):
+    def __init__(self, models, world_size: int | None = None, group=None, overlap: bool = False):
         self.models = list(models)
         self.params = [p for m in self.models for p in m.parameters() if p.requires_grad]
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.group = group
         self.flat = None
+        self.overlap = bool(overlap) and self.world > 1
+        self._works = {}
         # ONE buffer for the gradients of all models: the HIP backward of model i writes into slice i
-        # (rendering.FieldRender reads model._grad_target), so the step's exchange is a single collective
+        # (rendering._claim_grad_target reads model._grad_target)
         self.joint = None
-        try:
-            from . import ops
-            ps0 = [p for m in self.models for p in m.parameters()]
-            if ps0 and all(hasattr(m, "param_list") and sum(p.numel() for p in m.parameters()) == ops.PARAM_NUMEL
-                           for m in self.models) and all(p.is_cuda for p in ps0):
-                n = ops.PARAM_NUMEL
-                self.joint = torch.empty(len(self.models) * n, device=ps0[0].device, dtype=torch.float32)
-                for i, m in enumerate(self.models):
-                    m._grad_target = self.joint[i * n:(i + 1) * n]
-        except Exception:                       # foreign modules: per-model / loose paths below
-            self.joint = None
+        ps0 = [p for m in self.models for p in m.parameters()]
+        if ps0 and all(p.is_cuda for p in ps0) and all(
+                hasattr(m, "param_list") and hasattr(m, "grad_views")
+                and sum(p.numel() for p in m.param_list()) == getattr(m, "grad_numel", -1) for m in self.models):
+            # the models of this package (NeRF: 595 844 floats, SirenField: 529 156): slice i of the joint buffer
+            sizes = [m.grad_numel for m in self.models]
+            self.joint = torch.empty(sum(sizes), device=ps0[0].device, dtype=torch.float32)
+            off = 0
+            for i, (m, n) in enumerate(zip(self.models, sizes)):
+                m._grad_target = self.joint[off:off + n]
+                off += n
+                if self.overlap:
+                    m._grad_ready_hook = (lambda target, i=i: self._launch(i, target))
+
+    def _launch(self, i, target):
+        """Called by the model's backward right after its gradient kernels were enqueued into `target`."""
+        if i in self._works:
+            raise RuntimeError("FlatGradAllReduce(overlap=True): a model was applied more than once in one backward "
+                               "pass; its gradient slice is already being reduced")
+        self._works[i] = dist.all_reduce(target, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _bases(self):
         bases, loose = [], []
@@ -84,13 +103,24 @@ class FlatGradAllReduce:
         average=False leaves the SUM in the buffers: the caller folds 1/world into the optimizer
         (training.FusedAdam.step(grad_scale=1/world)) and saves a pass over the gradients."""
         bases, loose = self._bases()
+        works, self._works = self._works, {}
         if self.joint is not None and not loose and len(bases) == len(self.models) and all(
                 b.data_ptr() == m._grad_target.data_ptr() for b, m in zip(bases, self.models)):
-            if self.world > 1:                  # every model's gradients sit in the joint buffer: one collective
-                dist.all_reduce(self.joint, op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1:
+                if works:                       # slices already on the wire: wait for them, reduce the others now
+                    for i, m in enumerate(self.models):
+                        if i in works:
+                            works[i].wait()     # the compute stream waits for the collective
+                        else:
+                            dist.all_reduce(m._grad_target, op=dist.ReduceOp.SUM, group=self.group)
+                else:                           # every model's gradients sit in the joint buffer: one collective
+                    dist.all_reduce(self.joint, op=dist.ReduceOp.SUM, group=self.group)
                 if average:
                     self.joint.mul_(1.0 / self.world)
             return [self.joint]
+        if works:
+            raise RuntimeError("FlatGradAllReduce(overlap=True): a gradient slice was reduced early but the parameters' "
+                               "gradients no longer alias it (accumulated or chunked backward)")
         if self.world > 1:
             for b in bases:
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)

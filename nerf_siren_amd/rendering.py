@@ -47,21 +47,66 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, u=None):
     return ops.sample_pdf(bins, weights, N_importance, det=det, u=u)
 
 
+def _claim_grad_target(model, device):
+    """The views a backward pass may write a model's gradients into, or None (fresh buffer).
+
+    A data-parallel reducer may have given the model a slice of ONE buffer shared by all models
+    (parallel.FlatGradAllReduce).  The backward writes there ONCE per backward pass.  If the model is applied
+    several times in one graph (NeRFSystem.forward chunks a batch larger than hp.chunk; two render_rays calls summed into
+    one loss), autograd still holds the first contribution -- an alias of the target -- when the second node runs (p.grad
+    stays None until all of them have arrived), so every later contribution of the same pass goes to a fresh buffer and
+    autograd sums them.  The claim is released by an engine callback at the end of the pass.  Across passes: a
+    parameter that still holds a gradient in that very memory (zero_grad(set_to_none=False) / accumulation) also
+    forces a fresh buffer."""
+    target = getattr(model, "_grad_target", None)
+    if target is None or target.device != device:
+        return None
+    if getattr(model, "_grad_target_claimed", False):
+        if getattr(model, "_grad_ready_hook", None) is not None:
+            raise RuntimeError("FlatGradAllReduce(overlap=True) needs each model applied once per backward pass "
+                               "(its gradient slice is already being reduced)")
+        return None
+    lo, hi = target.data_ptr(), target.data_ptr() + target.numel() * 4
+    if any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in model.parameters()):
+        return None
+    model._grad_target_claimed = True
+
+    def release():
+        model._grad_target_claimed = False
+    torch.autograd.Variable._execution_engine.queue_callback(release)
+    return model.grad_views(target)
+
+
+def _grad_ready(model, claimed):
+    """The model's gradient kernels have been enqueued into its slice of the joint buffer: let an overlapping reducer
+    (parallel.FlatGradAllReduce(overlap=True)) put the slice on the wire while the other model's backward runs."""
+    hook = getattr(model, "_grad_ready_hook", None)
+    if claimed is not None and hook is not None:
+        hook(model._grad_target)
+
+
 class FieldRender(torch.autograd.Function):
     """inference() of rendering.py:105-190 for the full (rgb, sigma) branch:
-    (rays, z) -> rgb, depth, opacity, weights; gradients to the 24 parameters."""
+    (rays, z) -> rgb, depth, opacity, weights; gradients to the field's parameters (the 24 tensors of a NeRF, the 22
+    of a FiLM-SIREN field behind nerf.SirenField)."""
 
     @staticmethod
     def forward(ctx, model, rays, z, noise, noise_std, white_back, *params):
-        packed = model.packed()
-        if _MATH == "bf16x3":
-            field, saved = ops.nerf_forward_rays_fast(packed, model.packed_fast(), rays, z, sigma_only=False, save=True)
+        siren = hasattr(model, "field_rays")
+        if siren:
+            packed = model.model.packed()
+            field, saved = ops.siren_forward_rays_train(packed, rays, z, model.frequencies, model.phase_shifts, rays.shape[0])
+            ctx.fast = None
         else:
-            field, saved = ops.nerf_forward_rays(packed, rays, z, sigma_only=False, save=True)
+            packed = model.packed()
+            if _MATH == "bf16x3":
+                field, saved = ops.nerf_forward_rays_fast(packed, model.packed_fast(), rays, z, sigma_only=False, save=True)
+            else:
+                field, saved = ops.nerf_forward_rays(packed, rays, z, sigma_only=False, save=True)
+            ctx.fast = model.packed_fast() if _MATH == "bf16x3" else None
         weights, rgb, depth, opacity = ops.composite(field, z, rays, noise, noise_std, white_back)
         ctx.save_for_backward(rays, z, noise if noise is not None else rays.new_empty(0), field, saved, packed)
-        ctx.cfg = (noise is not None, float(noise_std), bool(white_back))
-        ctx.fast = model.packed_fast() if _MATH == "bf16x3" else None
+        ctx.cfg = (noise is not None, float(noise_std), bool(white_back), siren)
         ctx.model = model
         ctx.mark_non_differentiable(weights)
         ctx.set_materialize_grads(False)        # absent d/d(depth, opacity) arrive as None -> NULL in the C ABI
@@ -70,21 +115,38 @@ class FieldRender(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_opacity, _g_w):
         rays, z, noise, field, saved, packed = ctx.saved_tensors
-        has_noise, noise_std, white_back = ctx.cfg
+        has_noise, noise_std, white_back, siren = ctx.cfg
+        n_params = len(ops.SIREN_PARAM_ORDER if siren else ops.PARAM_ORDER)
         if g_rgb is None and g_depth is None and g_opacity is None:
-            return (None,) * (6 + len(ops.PARAM_ORDER))
+            return (None,) * (6 + n_params)
         grad_field = ops.composite_backward(field, z, rays, noise if has_noise else None, noise_std, white_back,
                                             g_rgb, g_depth, g_opacity)
-        # A data-parallel reducer may have given the model a slice of ONE buffer shared by all models
-        # (parallel.FlatGradAllReduce): write the gradients there, unless a parameter still holds a gradient in that very
-        # memory (zero_grad(set_to_none=False) / accumulation), in which case autograd must add into a fresh buffer.
-        target = getattr(ctx.model, "_grad_target", None)
-        out = None
-        if target is not None and target.device == rays.device:
-            lo, hi = target.data_ptr(), target.data_ptr() + target.numel() * 4
-            if not any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in ctx.model.parameters()):
-                out = ops.flat_views(target)
-        grads = ops.nerf_backward_rays(packed, rays, z, saved, grad_field, grads=out, fast=ctx.fast)
+        out = _claim_grad_target(ctx.model, rays.device)
+        if siren:
+            grads = ops.siren_backward(packed, saved, grad_field, ctx.model.frequencies, z.numel(), grads=out)
+        else:
+            grads = ops.nerf_backward_rays(packed, rays, z, saved, grad_field, grads=out, fast=ctx.fast)
+        _grad_ready(ctx.model, out)
+        return (None, None, None, None, None, None, *grads)
+
+
+class SirenPoints(torch.autograd.Function):
+    """SemanticNeRF.forward_with_frequencies_phase_shifts (nerf.py:201-216) with autograd w.r.t. the 22 parameters."""
+
+    @staticmethod
+    def forward(ctx, model, points, dirs, freq, phase, points_per_cond, *params):
+        packed = model.packed()
+        out, saved = ops.siren_forward_points_train(packed, points, dirs, freq, phase, points_per_cond)
+        ctx.save_for_backward(saved, packed, freq)
+        ctx.model, ctx.ppc = model, int(points_per_cond)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        saved, packed, freq = ctx.saved_tensors
+        out = _claim_grad_target(ctx.model, g_out.device)
+        grads = ops.siren_backward(packed, saved, g_out.contiguous(), freq, ctx.ppc, grads=out)
+        _grad_ready(ctx.model, out)
         return (None, None, None, None, None, None, *grads)
 
 
@@ -109,7 +171,7 @@ def _rng(rng, key, shape, device, kind):
 
 
 def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=0, noise_std=1, N_importance=0,
-                chunk=1024 * 32, white_back=False, test_time=False, _cls_num=6, network=None, *, rng=None):
+                chunk=1024 * 32, white_back=False, test_time=False, _cls_num=6, network=None, *, rng=None, aux=None):
     """Same positional signature and result dict as models/rendering.py:70-83, :262.
 
     models: [coarse] or [coarse, fine] nerf_siren_amd.NeRF; embeddings: [Embedding(3,10),
@@ -118,7 +180,10 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     chunk: accepted for compatibility; the fused kernels need no point chunking.
     rng (keyword-only, optional): dict of injected random draws in the reference's
     order -- 'perturb_rand' (N,S) [rendering.py:221], 'noise_coarse' (N,S) [:170],
-    'u' (N,F) [:47], 'noise_fine' (N,S+F); missing entries are drawn on the device.
+    'u' (N,F) [:47], 'noise_fine' (N,S+F); missing entries are drawn on the device.  'z_fine' (N,S+F), when given,
+    replaces the merged depths of :247 (parity tests condition the fine pass on the reference's own depths:
+    sample_pdf is ill-conditioned in ~zero-weight bins).
+    aux (keyword-only, optional): a dict that receives the intermediates 'z_coarse', 'weights_coarse', 'z_fine'.
     """
     if len(embeddings) != 2 or getattr(embeddings[0], "N_freqs", None) != 10 or \
             getattr(embeddings[1], "N_freqs", None) != 4:
@@ -131,9 +196,6 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     S, F = int(N_samples), int(N_importance)
     model_coarse = models[0]
     train = torch.is_grad_enabled() and any(p.requires_grad for m in models for p in m.parameters())
-    if train and any(hasattr(m, "field_rays") for m in models):
-        raise NotImplementedError("training through the FiLM-SIREN field is not implemented (the reference never "
-                                  "wires SemanticNeRF into training either); call under torch.no_grad()")
 
     pr = _rng(rng, "perturb_rand", (N, S), dev, "rand") if perturb > 0 else None
     z = ops.sample_stratified(rays, S, use_disp, float(perturb), pr)
@@ -145,13 +207,12 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
 
     def full_pass(model, zz, key):
         noise = noise_for(key, zz.shape[1])
-        if hasattr(model, "field_rays"):                       # FiLM-SIREN adapter (nerf.SirenField): inference
-            field = model.field_rays(rays, zz, sigma_only=False)
-            weights, rgb, depth, opacity = ops.composite(field, zz, rays, noise, noise_std, white_back)
-            return rgb, depth, opacity, weights
-        if train:
+        if train and any(p.requires_grad for p in model.param_list()):
             rgb, depth, opacity, weights = FieldRender.apply(model, rays, zz, noise, float(noise_std),
                                                             bool(white_back), *model.param_list())
+        elif hasattr(model, "field_rays"):                     # FiLM-SIREN adapter (nerf.SirenField)
+            field = model.field_rays(rays, zz, sigma_only=False)
+            weights, rgb, depth, opacity = ops.composite(field, zz, rays, noise, noise_std, white_back)
         else:
             field = _field_infer(model, rays, zz, False)
             weights, rgb, depth, opacity = ops.composite(field, zz, rays, noise, noise_std, white_back)
@@ -172,7 +233,13 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
 
     if F > 0:
         u = _rng(rng, "u", (N, F), dev, "rand") if perturb != 0 else None     # det = (perturb == 0), :243
-        z_fine = ops.importance_resample(z, weights_coarse, F, u)
+        z_fine = None if rng is None else rng.get("z_fine")
+        if z_fine is None:
+            z_fine = ops.importance_resample(z, weights_coarse, F, u)
+        elif tuple(z_fine.shape) != (N, S + F):
+            raise ValueError(f"rng['z_fine'] has shape {tuple(z_fine.shape)}, expected {(N, S + F)}")
+        if aux is not None:
+            aux.update(z_coarse=z, weights_coarse=weights_coarse, z_fine=z_fine)
         rgb, depth, op, _ = full_pass(models[1], z_fine, "noise_fine")
         result["rgb_fine"] = rgb
         result["depth_fine"] = depth

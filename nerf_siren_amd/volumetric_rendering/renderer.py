@@ -6,11 +6,18 @@ node (`_RenderFn`) whose backward is marcher(fine) -> unify^-1 -> marcher(coarse
 rendering_options may carry two extra keys to inject the reference's random draws (parity tests):
 'rng_stratified' (N,M,S,1) = the rand_like of sample_stratified, 'rng_importance' (N*M,F) = the rand of sample_pdf.
 """
+import weakref
+
 import torch
 
 from .. import eg3d_ops
 from .ray_marcher import MipRayMarcher2
 from . import math_utils
+
+
+# the reference calls a bare exit() here (renderer.py:139), which would take the caller's process down: an exception instead
+_NO_IMPORTANCE = ("ImportanceRenderer needs depth_resolution_importance > 0 (volumetric_rendering/renderer.py:122-139 has "
+                  "no coarse-only return)")
 
 
 def generate_planes():
@@ -90,14 +97,20 @@ class ImportanceRenderer(torch.nn.Module):
         super().__init__()
         self.ray_marcher = MipRayMarcher2()
         self.plane_axes = generate_planes()
-        self._planes_key = None
+        self._planes_src = None         # weak reference to the tensor OBJECT the cached image was packed from
+        self._planes_ver = None
         self._planes_hwc = None
 
     def _pack(self, planes):
-        key = (planes.data_ptr(), planes._version, tuple(planes.shape))
-        if key != self._planes_key:
+        """Channels-last image of `planes`, cached only while the SAME tensor object (weak reference) is passed again at
+        the same version.  Never keyed on the address: in the reference planes is a fresh backbone.synthesis() output on
+        every call (eg3d_training/triplane.py:61-65) and the caching allocator hands a freed activation's address --
+        with _version 0 -- straight back to the next one."""
+        src = self._planes_src() if self._planes_src is not None else None
+        if src is not planes or self._planes_ver != planes._version or self._planes_hwc is None:
             self._planes_hwc = eg3d_ops.pack_planes(planes)
-            self._planes_key = key
+            self._planes_src = weakref.ref(planes)
+            self._planes_ver = planes._version
         return self._planes_hwc
 
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
@@ -126,7 +139,7 @@ class ImportanceRenderer(torch.nn.Module):
                 raise NotImplementedError("density_noise is not supported in training mode")
             F_ = opts['depth_resolution_importance']
             if F_ <= 0:
-                raise SystemExit
+                raise ValueError(_NO_IMPORTANCE)
             u_ = opts.get('rng_importance')
             u_ = torch.rand((N * M, F_), device=dev) if u_ is None else u_.reshape(N * M, F_)
             net = decoder.net
@@ -145,7 +158,7 @@ class ImportanceRenderer(torch.nn.Module):
 
         F = opts['depth_resolution_importance']
         if F <= 0:
-            raise SystemExit                                                     # the reference calls exit() (renderer.py:139)
+            raise ValueError(_NO_IMPORTANCE)
         u = opts.get('rng_importance')
         u = torch.rand((N * M, F), device=dev) if u is None else u.reshape(N * M, F)
         depths_fine = eg3d_ops.sample_importance(depths_coarse, weights_coarse, u)

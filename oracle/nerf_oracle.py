@@ -407,31 +407,72 @@ def render_rays_backward(params, res, grads, white_back=False):
 # a7  FiLM-SIREN field: FiLMLayer (nerf.py:142-151) and
 #     SemanticNeRF.forward_with_frequencies_phase_shifts (nerf.py:201-216)
 # ----------------------------------------------------------------------------
-def film_layer(w, b, x, freq, phase):
+def film_layer(w, b, x, freq, phase, keep: bool = False):
     """FiLMLayer.forward: sin(freq * (x W^T + b) + phase); freq/phase (Bz,H) broadcast over points."""
     y = (x @ w.T + b).astype(F32)
     arg = ((freq[:, None, :] * y).astype(F32) + phase[:, None, :]).astype(F32)
-    return np.sin(arg.astype(F64)).astype(F32)
+    out = np.sin(arg.astype(F64)).astype(F32)
+    return (out, arg) if keep else out
 
 
-def siren_forward(p: dict, inp, frequencies, phase_shifts, ray_directions, sigma_only: bool = False):
-    """inp (Bz,Np,3), frequencies/phase_shifts (Bz, 9*256), ray_directions (Bz,Np,3) -> (Bz,Np,4) [rgb,sigma]."""
+def siren_forward(p: dict, inp, frequencies, phase_shifts, ray_directions, sigma_only: bool = False,
+                  keep: bool = False):
+    """inp (Bz,Np,3), frequencies/phase_shifts (Bz, 9*256), ray_directions (Bz,Np,3) -> (Bz,Np,4) [rgb,sigma].
+    keep=True also returns the cache siren_backward needs."""
     inp = np.asarray(inp, F32)
     H = 256
     fr = ((np.asarray(frequencies, F32) * F32(15)).astype(F32) + F32(30)).astype(F32)       # nerf.py:202
     ph = np.asarray(phase_shifts, F32)
     x = (inp * F32(2.0 / 51.0)).astype(F32)                                                   # UniformBoxWarp(51), :134-140,:193
+    xs, args = [], []
     for i in range(8):
-        x = film_layer(p[f"network.{i}.layer.weight"], p[f"network.{i}.layer.bias"], x,
-                       fr[:, i * H:(i + 1) * H], ph[:, i * H:(i + 1) * H])
+        xs.append(x)
+        x, a = film_layer(p[f"network.{i}.layer.weight"], p[f"network.{i}.layer.bias"], x,
+                          fr[:, i * H:(i + 1) * H], ph[:, i * H:(i + 1) * H], keep=True)
+        args.append(a)
     sigma = (x @ p["final_layer.weight"].T + p["final_layer.bias"]).astype(F32)
     if sigma_only:
-        return sigma
+        return (sigma, dict(xs=xs, args=args, h=x, fr=fr)) if keep else sigma
     cin = np.concatenate([np.asarray(ray_directions, F32), x], -1)                            # :213
-    c = film_layer(p["color_layer_sine.layer.weight"], p["color_layer_sine.layer.bias"], cin, fr[:, -H:], ph[:, -H:])
+    c, carg = film_layer(p["color_layer_sine.layer.weight"], p["color_layer_sine.layer.bias"], cin, fr[:, -H:], ph[:, -H:],
+                         keep=True)
     pre = (c @ p["color_layer_linear.0.weight"].T + p["color_layer_linear.0.bias"]).astype(F32)
     rgb = (F32(1) / (F32(1) + np.exp(-pre.astype(F64)))).astype(F32)
-    return np.concatenate([rgb, sigma], -1).astype(F32)
+    out = np.concatenate([rgb, sigma], -1).astype(F32)
+    if keep:
+        return out, dict(xs=xs, args=args, h=x, fr=fr, cin=cin, c=c, carg=carg, rgb=rgb)
+    return out
+
+
+def siren_backward(p: dict, cache: dict, grad_out: np.ndarray) -> dict:
+    """Manual backward of siren_forward (autograd of nerf.py:142-151, :201-216) w.r.t. the 22 parameters.
+    grad_out (Bz,Np,4) = [d rgb, d sigma].  d/dz sin(fr*z + ph) = fr * cos(fr*z + ph)."""
+    H = 256
+    fr = cache["fr"]
+    g = {}
+
+    def flat(a):
+        return a.reshape(-1, a.shape[-1])
+
+    d_rgb, d_sigma = grad_out[..., :3], grad_out[..., 3:4]
+    rgb = cache["rgb"]
+    d_pre = (d_rgb * rgb * (F32(1) - rgb)).astype(F32)                                       # sigmoid, :214
+    g["color_layer_linear.0.weight"] = flat(d_pre).T @ flat(cache["c"])
+    g["color_layer_linear.0.bias"] = flat(d_pre).sum(0)
+    d_c = d_pre @ p["color_layer_linear.0.weight"]
+    dz = (d_c * fr[:, None, -H:] * np.cos(cache["carg"].astype(F64)).astype(F32)).astype(F32)
+    g["color_layer_sine.layer.weight"] = flat(dz).T @ flat(cache["cin"])                      # columns [dir 3 | hidden 256], :213
+    g["color_layer_sine.layer.bias"] = flat(dz).sum(0)
+    d_h = (dz @ p["color_layer_sine.layer.weight"])[..., 3:] + d_sigma @ p["final_layer.weight"]
+    g["final_layer.weight"] = flat(d_sigma).T @ flat(cache["h"])
+    g["final_layer.bias"] = flat(d_sigma).sum(0)
+    for i in reversed(range(8)):
+        dz = (d_h * fr[:, None, i * H:(i + 1) * H] * np.cos(cache["args"][i].astype(F64)).astype(F32)).astype(F32)
+        g[f"network.{i}.layer.weight"] = flat(dz).T @ flat(cache["xs"][i])
+        g[f"network.{i}.layer.bias"] = flat(dz).sum(0)
+        if i:
+            d_h = dz @ p[f"network.{i}.layer.weight"]
+    return {k: np.asarray(v, F32) for k, v in g.items()}
 
 
 # ----------------------------------------------------------------------------

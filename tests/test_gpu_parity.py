@@ -291,11 +291,27 @@ def _run_hip(g, dev, ms, grad=False):
                            bool(g["test_time"]), rng=rng)
 
 
+def _midpoints(z):
+    return 0.5 * (z[:, :-1] + z[:, 1:])
+
+
 @pytest.mark.parametrize("case", RENDER_CASES)
-def test_render_rays_vs_reference_and_oracle(golden, dev, models, case):
+def test_render_rays_vs_reference_and_oracle(golden, dev, models, ops, case):
+    """Free-running render_rays against the reference's outputs and the oracle's.  Coarse outputs: 1e-4 on every ray.
+    Fine outputs: 1e-4 on every ray whose 64 sample_pdf indices AND merged depths agree with the reference's; the 100x
+    bound applies ONLY to rays where an index flipped or a depth moved (sample_pdf is ill-conditioned in ~zero-weight
+    bins), and the rate of such rays / indices is bounded and printed."""
     g = golden("g7_" + case)
     params, ms = models
-    res = _run_hip(g, dev, ms)
+    aux = {}
+    F = int(g["F"])
+    from nerf_siren_amd import Embedding, render_rays
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    hrng = {k[4:]: T(g[k], dev) for k in g if k.startswith("rng_")}
+    with torch.no_grad():
+        res = render_rays(ms if F > 0 else ms[:1], emb, T(g["rays"], dev), int(g["S"]), bool(g["use_disp"]),
+                          float(g["perturb"]), float(g["noise_std"]), F, 1024 * 32, bool(g["white_back"]),
+                          bool(g["test_time"]), rng=hrng, aux=aux)
     keys = [k[4:] for k in g if k.startswith("out_")]
     assert list(res.keys()) == keys                          # same keys, same order as the reference
     rng = {k[4:]: g[k] for k in g if k.startswith("rng_")}
@@ -303,17 +319,56 @@ def test_render_rays_vs_reference_and_oracle(golden, dev, models, case):
                         float(g["noise_std"]), int(g["F"]), bool(g["white_back"]), bool(g["test_time"]), rng=rng)
     n = g["rays"].shape[0]
     span = float((g["rays"][:, 7] - g["rays"][:, 6]).max())
+    moved = {"reference": np.zeros(n, bool), "oracle": np.zeros(n, bool)}
+    if F > 0:
+        # the HIP path's own sample_pdf indices (nerfmi_sample_pdf is bit-identical to the fused resampling kernel,
+        # test_importance_resample) against the reference's recorded torch.searchsorted output
+        zc, wc = aux["z_coarse"], aux["weights_coarse"]
+        det = float(g["perturb"]) == 0
+        _, _, inds = ops.sample_pdf(_midpoints(zc), wc[:, 1:-1].contiguous(), F, det=det,
+                                    u=None if det else hrng["u"], return_aux=True)
+        zf = N(aux["z_fine"])
+        for name, ref_inds, ref_z in (("reference", g["mid_inds"], g["mid_sort_out"]),
+                                      ("oracle", ref["_aux"]["inds"], ref["_aux"]["z_fine"])):
+            mism = N(inds) != ref_inds
+            dz = np.abs(zf - ref_z).max(-1) > 1e-5 * span
+            moved[name] = mism.any(1) | dz
+            print(f"[{case}] HIP vs {name}: index agreement {100 * (1 - mism.mean()):.3f} % of {mism.size} indices, "
+                  f"rays with a flipped index {mism.any(1).mean():.3f}, rays with a moved depth {dz.mean():.3f}")
+            assert mism.mean() < 0.03, (name, mism.mean())                 # >= 97 % index agreement
+            # rays with >= 1 moved sample: in deterministic mode the u = 1.0 edge sits on the ulp of cdf[-1] (SURVEY
+            # section 7 measured 18-49 % of rays for any valid re-association of the row sum); with random u a few %
+            assert moved[name].mean() <= (0.5 if det else 0.25), (name, moved[name].mean())
     for k in keys:
         v = N(res[k])
         assert v.shape == g["out_" + k].shape and v.dtype == np.float32
         tol = 1e-4 * (span if "depth" in k else 1.0)
         for name, target in (("reference", g["out_" + k]), ("oracle", ref[k])):
             err = np.abs(v - target).reshape(n, -1).max(-1)
-            # rays whose fine samples moved (1-ulp cdf / flipped index): looser, must be few
-            bad = err > tol
-            assert bad.mean() <= 0.35 and np.all(err <= 100 * tol), (k, name, err.max(), bad.mean())
-            if "coarse" in k:
-                assert not bad.any(), (k, name, err.max())
+            loose = moved[name] & ("fine" in k)
+            assert np.all(err[~loose] <= tol), (k, name, err[~loose].max())
+            assert np.all(err[loose] <= 100 * tol), (k, name, err[loose].max())
+
+
+@pytest.mark.parametrize("case", [c for c in RENDER_CASES if c != "coarse_only"])
+def test_render_rays_fine_pass_on_reference_depths(golden, dev, models, case):
+    """The fine MLP + compositor held to the strict tolerance on ALL rays: the merged depths of rendering.py:247 are
+    injected from the reference's own run (mid_sort_out), so sample_pdf's conditioning is out of the picture."""
+    g = golden("g7_" + case)
+    _, ms = models
+    from nerf_siren_amd import Embedding, render_rays
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    hrng = {k[4:]: T(g[k], dev) for k in g if k.startswith("rng_")}
+    hrng["z_fine"] = T(g["mid_sort_out"], dev)
+    with torch.no_grad():
+        res = render_rays(ms, emb, T(g["rays"], dev), int(g["S"]), bool(g["use_disp"]), float(g["perturb"]),
+                          float(g["noise_std"]), int(g["F"]), 1024 * 32, bool(g["white_back"]), bool(g["test_time"]),
+                          rng=hrng)
+    span = float((g["rays"][:, 7] - g["rays"][:, 6]).max())
+    for k in res:
+        tol = 1e-4 * (span if "depth" in k else 1.0)
+        err = np.abs(N(res[k]) - g["out_" + k])
+        assert err.max() <= tol, (k, err.max())
 
 
 def test_render_rays_full_size_properties(dev, models):
@@ -504,8 +559,110 @@ def test_siren_render_rays(dev, siren, ops, math):
         sa = ops.siren_forward_rays_fast(m.packed(), m.packed_fast(), T(rays, dev), zz, T(freq, dev), T(phase, dev), 37,
                                          sigma_only=True)
         np.testing.assert_allclose(N(sa)[:, 0], N(b)[:, 3], rtol=0, atol=1e-6)
+
+
+def _rel(a, b):
+    return float(np.linalg.norm((a - b).astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+def test_siren_backward_vs_reference_autograd(golden, dev, siren):
+    """Gradients of all 22 parameters through SemanticNeRF.forward_with_frequencies_phase_shifts against the
+    REFERENCE's autograd (fixture g8b, tools/make_golden.py:g_siren) and the oracle's manual backward.  Three
+    conditioning rows of 41 points: the waves straddle conditioning rows and the last tile is ragged."""
+    g, gg = golden("g8_siren"), golden("g8b_siren_grad")
+    p, m = siren
+    m.zero_grad()
+    args = [T(g[k], dev) for k in ("inp", "freq", "phase", "dirs")]
+    out = m.forward_with_frequencies_phase_shifts(*args)
+    assert out.requires_grad
+    np.testing.assert_allclose(N(out), gg["out"], atol=1e-4)
+    (out * T(gg["G"], dev)).sum().backward()
+    o, cache = O.siren_forward(p, g["inp"], g["freq"], g["phase"], g["dirs"], keep=True)
+    og = O.siren_backward(p, cache, gg["G"])
+    first = {}
+    for k, q in m.named_parameters():
+        assert q.grad is not None and q.grad.shape == q.shape, k
+        first[k] = N(q.grad).copy()
+        r_ref, r_or = _rel(first[k], gg["grad_" + k]), _rel(first[k], og[k])
+        assert r_ref < 2e-4 and r_or < 2e-4, (k, r_ref, r_or)      # typical 5e-6 (no ReLU kinks in this field)
+    # bit-reproducible (fixed-order slab reduction, no float atomics), and written -- not accumulated -- by the kernel
+    m.zero_grad()
+    (m.forward_with_frequencies_phase_shifts(*args) * T(gg["G"], dev)).sum().backward()
+    for k, q in m.named_parameters():
+        assert np.array_equal(N(q.grad), first[k]), k
+    m.zero_grad()
     with pytest.raises(NotImplementedError):
-        render_rays([f, f], emb, T(rays, dev), 64, False, 0, 0, 64, 1024 * 32, True, False)   # grad mode
+        m.forward_with_frequencies_phase_shifts(args[0].requires_grad_(True), *args[1:])
+
+
+@pytest.mark.parametrize("n_rays", [37, 200])
+def test_siren_render_rays_training(dev, n_rays):
+    """render_rays([SirenField, SirenField]) in training mode (perturb, noise, white_back) against the oracle pipeline:
+    outputs, and the gradients of both fields' 22 parameters (compositor backward -> SIREN backward).  The fine
+    pass is conditioned on the oracle's merged depths (rng['z_fine'])."""
+    from nerf_siren_amd import Embedding, SemanticNeRF, SirenField, render_rays
+    ps = [synth.siren_params(3), synth.siren_params(4)]
+    conds = [(synth.hash_normal((1, 2304), 311 + i), synth.hash_normal((1, 2304), 321 + i)) for i in range(2)]
+    for p in ps:                                   # a field with some opacity: sigma bias up
+        p["final_layer.bias"] = p["final_layer.bias"] + np.float32(0.3)
+        p["final_layer.weight"] = p["final_layer.weight"] * np.float32(20)
+    fields = []
+    for p, (fr, ph) in zip(ps, conds):
+        m = SemanticNeRF()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+        fields.append(SirenField(m, torch.from_numpy(fr), torch.from_numpy(ph)).to(dev))
+    S = F = 64
+    rays = synth.blender_rays(n_rays, 34)
+    rng = dict(perturb_rand=synth.hash_uniform((n_rays, S), 330), noise_coarse=synth.hash_normal((n_rays, S), 331),
+               u=synth.hash_uniform((n_rays, F), 332), noise_fine=synth.hash_normal((n_rays, S + F), 333))
+    # ---- oracle pipeline
+    d3 = rays[:, 3:6]
+
+    def field(i, z):
+        pts = O.points(rays, z)
+        dirs = np.repeat(d3[:, None], z.shape[1], 1)
+        o, c = O.siren_forward(ps[i], pts.reshape(1, -1, 3), conds[i][0], conds[i][1], dirs.reshape(1, -1, 3), keep=True)
+        return o.reshape(n_rays, z.shape[1], 4), c
+    z = O.sample_z(rays, S, False, 1.0, rng["perturb_rand"])
+    oc, cache_c = field(0, z)
+    cc = O.composite(oc[..., 3], oc[..., :3], z, d3, rng["noise_coarse"], 1.0, True, True)
+    z_new, _ = O.sample_pdf(O.midpoints(z), cc["weights"][:, 1:-1], F, det=False, u=rng["u"])
+    z_fine = np.sort(np.concatenate([z, z_new], -1), -1)
+    of, cache_f = field(1, z_fine)
+    cf = O.composite(of[..., 3], of[..., :3], z_fine, d3, rng["noise_fine"], 1.0, True, True)
+    # ---- HIP
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    hr = {k: T(v, dev) for k, v in rng.items()}
+    hr["z_fine"] = T(z_fine, dev)
+    res = render_rays(fields, emb, T(rays, dev), S, False, 1.0, 1.0, F, 1024 * 32, True, False, rng=hr)
+    for k, ref in (("rgb_coarse", cc["rgb"]), ("depth_coarse", cc["depth"]), ("opacity_coarse", cc["opacity"]),
+                   ("rgb_fine", cf["rgb"]), ("depth_fine", cf["depth"]), ("opacity_fine", cf["opacity"])):
+        assert res[k].requires_grad
+        np.testing.assert_allclose(N(res[k]), ref, atol=1e-4 * (4.0 if "depth" in k else 1.0), err_msg=k)
+    G = {k: synth.hash_normal(tuple(v.shape), 340 + i) for i, (k, v) in enumerate(res.items())}
+    sum((res[k] * T(G[k], dev)).sum() for k in res).backward()
+    for tag, i, cres, cache in (("coarse", 0, cc, cache_c), ("fine", 1, cf, cache_f)):
+        d_s, d_rgb = O.composite_backward(cres["_cache"], cres["weights"], G["rgb_" + tag], G["depth_" + tag],
+                                          G["opacity_" + tag], True)
+        og = O.siren_backward(ps[i], cache, np.concatenate([d_rgb, d_s[..., None]], -1).reshape(1, -1, 4))
+        for k, q in fields[i].model.named_parameters():
+            assert q.grad is not None, (tag, k)
+            r = _rel(N(q.grad), og[k])
+            assert r < 5e-4, (tag, k, r)
+        assert fields[i].frequencies.grad is None
+    # a short optimisation run through the same path makes progress (FusedAdam on the SIREN parameters)
+    from nerf_siren_amd.training import FusedAdam
+    opt = FusedAdam(fields, lr=1e-4)
+    target = T(synth.hash_uniform((n_rays, 3), 350), dev)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad(set_to_none=True)
+        r = render_rays(fields, emb, T(rays, dev), S, False, 1.0, 0.0, F, 1024 * 32, True, False, rng=hr)
+        loss = ((r["rgb_coarse"] - target) ** 2).mean() + ((r["rgb_fine"] - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses
 
 
 # --------------------------------------------------------------------------- EG3D (a9-a14)

@@ -220,6 +220,22 @@ def test_siren_oracle_vs_reference(golden):
     assert np.array_equal(sig[..., 0], out[..., 3])
 
 
+def test_siren_backward_oracle_vs_reference_autograd(golden):
+    """Manual backward of the FiLM-SIREN field vs the reference's autograd (all 22 parameter gradients of
+    loss = sum(out * G) through the imported SemanticNeRF, tools/make_golden.py:g_siren)."""
+    g, gg = golden("g8_siren"), golden("g8b_siren_grad")
+    p = synth.siren_params(3)
+    out, cache = O.siren_forward(p, g["inp"], g["freq"], g["phase"], g["dirs"], keep=True)
+    assert np.abs(out - gg["out"]).max() < 2e-6
+    grads = O.siren_backward(p, cache, gg["G"])
+    assert set(grads) == set(p)
+    for k, v in grads.items():
+        ref = gg["grad_" + k]
+        assert v.shape == ref.shape, k
+        rel = np.linalg.norm((v - ref).astype(np.float64)) / max(np.linalg.norm(ref.astype(np.float64)), 1e-30)
+        assert rel < 2e-5, (k, rel)
+
+
 # --------------------------------------------------------------------------- f2: loss + Adam
 @pytest.mark.parametrize("tag", ["c64", "c1000", "coarse_only"])
 def test_mse_loss_oracle_vs_reference(golden, tag):
@@ -345,3 +361,45 @@ def test_bf16_three_way_split_is_exact():
     exact = a.astype(np.float64) * b.astype(np.float64)
     ok = np.isfinite(exact) & (np.abs(exact) > 1e-30) & (np.abs(exact) < 1e30)
     assert np.abs(kept[ok] / exact[ok] - 1).max() < 2.0 ** -22
+
+
+# --------------------------------------------------------------------------- cpu_baseline: the torch-CPU restatement
+@pytest.mark.parametrize("case", RENDER_CASES)
+def test_torch_cpu_ref_vs_reference(golden, case):
+    """oracle/torch_cpu_ref.py (what bench.py times as `cpu_baseline`) runs the reference's torch op sequence: on the
+    G7 fixtures (outputs and autograd gradients of the imported reference, captured draws injected) it must reproduce
+    the reference to rounding."""
+    import torch
+    from oracle import torch_cpu_ref as TR
+    g = golden("g7_" + case)
+    F, test_time = int(g["F"]), bool(g["test_time"])
+    ps = [synth.nerf_params(1, sigma_bias=-1.0), synth.nerf_params(2, sigma_bias=0.5)]
+    params = [{k: torch.from_numpy(v.copy()).requires_grad_(not test_time) for k, v in p.items()} for p in ps]
+    rng = {k[4:]: torch.from_numpy(g[k]) for k in g if k.startswith("rng_")}
+    res = TR.render_rays(params, torch.from_numpy(g["rays"]), int(g["S"]), bool(g["use_disp"]), float(g["perturb"]),
+                         float(g["noise_std"]), F, 1024 * 32, bool(g["white_back"]), test_time, rng=rng)
+    keys = [k[4:] for k in g if k.startswith("out_")]
+    assert list(res.keys()) == keys
+    for k in keys:
+        np.testing.assert_allclose(res[k].detach().numpy(), g["out_" + k], rtol=0, atol=2e-6, err_msg=k)
+    if test_time:
+        return
+    t = torch.from_numpy(g["target"])
+    loss = ((res["rgb_coarse"] - t) ** 2).mean() + 0.1 * res["depth_coarse"].mean() + 0.3 * res["opacity_coarse"].mean()
+    if F > 0:
+        loss = loss + ((res["rgb_fine"] - t) ** 2).mean() + 0.2 * (res["depth_fine"] ** 2).mean() \
+            - 0.1 * res["opacity_fine"].mean()
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-6)
+    gs = [{k: v.grad.numpy() for k, v in p.items()} if mi == 0 or F > 0 else None for mi, p in enumerate(params)]
+    w = grad_rel_errors(g, gs)
+    assert max(w) < 1e-4, w
+
+
+def test_torch_cpu_ref_host_info_and_sample():
+    from oracle import torch_cpu_ref as TR
+    info = TR.host_info()
+    assert info["physical_cores"] >= 1 and 1 <= info["threads"] <= info["nproc"] and info["cpu_model"]
+    ps = [synth.nerf_params(1, False), synth.nerf_params(2, False)]
+    out = TR.timed_sample("infer", ps, lambda i: synth.blender_rays(64, seed=i), None, budget_s=0.2, n_rays=64, max_steps=2)
+    assert out["steps"] >= 1 and out["ray_samples_per_s"] > 0 and "parallel_info" in out

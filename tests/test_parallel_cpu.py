@@ -82,3 +82,52 @@ def test_shard_rays_partition():
         spans = [shard_rays(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+class _ToyModel(torch.nn.Module):
+    """Stands in for NeRF on the CPU: one weight vector, gradients written into model._grad_target by the backward."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor([1.0, 2.0, 3.0, 4.0]))
+        self._grad_target = torch.zeros(4)
+
+    def grad_views(self, flat):
+        return [flat[0:4]]
+
+
+class _ToyRender(torch.autograd.Function):
+    """Same write-into-the-shared-target protocol as rendering.FieldRender.backward."""
+
+    @staticmethod
+    def forward(ctx, model, scale, w):
+        ctx.model, ctx.scale = model, scale
+        return (w * scale).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        from nerf_siren_amd.rendering import _claim_grad_target
+        out = _claim_grad_target(ctx.model, torch.device("cpu"))
+        val = torch.full((4,), float(ctx.scale)) * g
+        if out is None:
+            return None, None, val
+        out[0].copy_(val)
+        return None, None, out[0]
+
+
+def test_grad_target_is_claimed_once_per_backward_pass():
+    """A model applied twice in ONE graph (NeRFSystem.forward chunking, two render_rays calls in one loss): the second
+    backward node must not overwrite the first contribution that autograd still holds as an alias of the shared target
+    (round-1 advisor finding: [2,4,6,8]-style doubling instead of the sum)."""
+    m = _ToyModel()
+    loss = _ToyRender.apply(m, 1.0, m.w) + _ToyRender.apply(m, 10.0, m.w)
+    loss.backward()
+    assert torch.equal(m.w.grad, torch.full((4,), 11.0))
+    assert not m._grad_target_claimed                      # released at the end of the pass
+    # next pass, gradient cleared: the target is written again (no copy), and is the gradient's memory
+    m.w.grad = None
+    _ToyRender.apply(m, 3.0, m.w).backward()
+    assert torch.equal(m.w.grad, torch.full((4,), 3.0)) and m.w.grad.data_ptr() == m._grad_target.data_ptr()
+    # accumulation across passes (grad not cleared, still aliasing the target): must add, not overwrite
+    _ToyRender.apply(m, 5.0, m.w).backward()
+    assert torch.equal(m.w.grad, torch.full((4,), 8.0))

@@ -314,6 +314,14 @@ def g_siren():
                             torch.from_numpy(freq[:, :256]), torch.from_numpy(phase[:, :256]))
     save("g8_siren", inp=inp, dirs=dirs, freq=freq, phase=phase, out=out, film_in=synth.hash_normal((Bz, Np, 256), 204),
          film_out=film, n_params=sum(q.numel() for q in m.parameters()))
+    # G8b: the reference's autograd through SemanticNeRF (nerf.py:142-151, :201-216): gradients of all 22 parameters of
+    # loss = sum(out * G), inputs as above (three conditioning rows, 41 points each)
+    G = synth.hash_normal((Bz, Np, 4), 205)
+    m.zero_grad()
+    o = m.forward_with_frequencies_phase_shifts(torch.from_numpy(inp), torch.from_numpy(freq), torch.from_numpy(phase),
+                                                torch.from_numpy(dirs))
+    (o * torch.from_numpy(G)).sum().backward()
+    save("g8b_siren_grad", G=G, out=o, **{"grad_" + k: q.grad for k, q in m.named_parameters()})
 
 
 # --------------------------------------------------------------------------- G9..G14 (EG3D)
