@@ -6,20 +6,30 @@
 One "step" = one pass of the hot path over one batch of 1024 rays per rank:
   --mode train (default): render_rays forward (coarse+fine, perturb=1,
       noise_std=1) + MSE(coarse)+MSE(fine) + backward through both MLPs +
-      gradient all-reduce (RCCL, N>1) + Adam step  -- system.py:257-275
+      gradient all-reduce (RCCL, N>1; the fine model's slice goes on the wire while the
+      coarse model's backward runs) + Adam step  -- system.py:257-275
   --mode infer: render_rays(test_time=True, perturb=0, noise_std=0) under
       no_grad -- eval.py:85-96
 A ray-sample = one field evaluation: 64 coarse + 128 fine = 192 per ray.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fine
-NeRF MLP forward, fp32 MFMA bound): algorithmic FLOPs per launch / its average
-duration measured with HIP events on the launch stream inside the timed region.
-`cpu_baseline` is the numpy oracle timed on this box's host cores on a bounded
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (a child
+`python -m torch.distributed.run`, before this process makes any GPU call) and relays rank 0's JSON line; under
+torch.distributed.run it is one rank.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fine NeRF MLP forward, fp32 MFMA bound):
+algorithmic FLOPs per launch / its average duration measured with HIP events on the launch stream inside the timed
+region (ops.set_profile_hook).  Beside the headline, at N = 1: `infer` (the same field at test time), `siren` (the
+FiLM-SIREN field of configs[1]: training and inference steps + the roofline of siren_forward_kernel), `eg3d`
+(configs[4]: ImportanceRenderer forward / forward+backward / dense 128^3 query with the gather roofline of
+triplane_kernel), `opt_in` (split-bf16 math), `psnr` (committed teacher-scene protocol) and `cpu_baseline` = the
+reference's CPU PyTorch path restated op for op (oracle/torch_cpu_ref.py) on this box's physical cores, on a bounded
 sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +41,7 @@ FLOP_SIGMA = 982_528         # sigma-only forward per sample
 FLOP_TRAIN = 3_489_024       # fwd + dW + dX per sample
 FLOP_SIREN = 1_053_696       # FiLM-SIREN full forward per sample (+2 304 sin)
 PEAK_F32_MFMA = 157.3        # TFLOP/s dense (MI355X_MICROARCH.md)
+PEAK_HBM = 8.0               # TB/s
 
 
 def parse():
@@ -41,66 +52,77 @@ def parse():
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--batch", type=int, default=1024, help="rays per rank per step (configs[1])")
     ap.add_argument("--field", choices=["nerf", "siren"], default="nerf",
-                    help="nerf = the reference's live 8x256 ReLU NeRF; siren = its FiLM-SIREN field (inference only)")
+                    help="headline field: nerf = the reference's live 8x256 ReLU NeRF (system.py:183-190); siren = its "
+                         "FiLM-SIREN field (always reported in the `siren` object at N = 1)")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="fp32",
-                    help="fp32 = exact fp32 MFMA (default); bf16x3 = opt-in split-bf16 inference math (--mode infer)")
+                    help="fp32 = exact fp32 MFMA (default); bf16x3 = opt-in split-bf16 math")
     ap.add_argument("--optimizer", choices=["fused", "torch"], default="fused",
                     help="training: nerf_siren_amd.training.FusedAdam + FusedMSELoss (one launch each) or torch.optim.Adam "
                          "+ elementwise loss -- same arithmetic")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: one joint all-reduce after the whole backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true", help="skip the PSNR-parity check (tests/golden/g15_psnr.npz protocol)")
     ap.add_argument("--no-opt-in", action="store_true", help="skip the extra timed loop on the opt-in split-bf16 math")
+    ap.add_argument("--no-extra", action="store_true", help="skip the infer / siren / eg3d objects")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work in the bounded cpu_baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(mode, budget_s=12.0, chunk=256, max_rays=8192):
-    """numpy oracle (kind 'port') on the host cores: chunks of `chunk` rays of the same workload until
-    ~budget_s seconds of CPU work are done (bounded sample; the chunking only bounds memory)."""
+# -------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks as children BEFORE anything here touches the GPU
+# -------------------------------------------------------------------------------------------------
+def spawn_ranks(n: int) -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# -------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's torch-CPU path (restated), all physical cores
+# -------------------------------------------------------------------------------------------------
+def cpu_baseline(mode, budget_s=12.0):
     from nerf_siren_amd import synth
-    from oracle import nerf_oracle as O
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    params = [synth.nerf_params(1, False), synth.nerf_params(2, False)]
-    done, dt, i = 0, 0.0, 0
-    while dt < budget_s and done < max_rays:
-        n = chunk
-        rays = synth.blender_rays(n, seed=123 + i)
-        t0 = time.perf_counter()
-        if mode == "infer":
-            O.render_rays(params, rays, 64, False, 0.0, 0.0, 64, True, True)
-        else:
-            rng = {"perturb_rand": synth.hash_uniform((n, 64), 1), "noise_coarse": synth.hash_normal((n, 64), 2),
-                   "u": synth.hash_uniform((n, 64), 3), "noise_fine": synth.hash_normal((n, 128), 4)}
-            res = O.render_rays(params, rays, 64, False, 1.0, 1.0, 64, True, False, rng=rng, keep=True)
-            tgt = synth.hash_uniform((n, 3), 5)
-            g = {"rgb_coarse": 2 * (res["rgb_coarse"] - tgt) / (3 * n), "rgb_fine": 2 * (res["rgb_fine"] - tgt) / (3 * n)}
-            O.render_rays_backward(params, res, g, True)
-        dt += time.perf_counter() - t0
-        done += n
-        i += 1
-    return {"value": done * 192 / dt, "unit": "ray-samples/s", "cores": int(cores), "kind": "port",
-            "sample": f"{done} rays x (64+128) samples in chunks of {chunk}, {mode} step "
-                      f"(fwd{'+bwd' if mode == 'train' else ''}), numpy oracle, {dt:.1f} s"}
+    from oracle import torch_cpu_ref as TR
+    ps = [synth.nerf_params(1, False), synth.nerf_params(2, False)]
+    r = TR.timed_sample(mode, ps, lambda i: synth.blender_rays(1024, seed=123 + i),
+                        lambda i: synth.hash_uniform((1024, 3), 5 + i), budget_s=budget_s, n_rays=1024)
+    return {"value": r["ray_samples_per_s"], "unit": "ray-samples/s", "cores": r["threads"], "kind": "port",
+            "sample": f"{r['steps']} steps of 1024 rays x (64+128) samples, {mode} step "
+                      f"({'fwd+MSE+bwd+Adam' if mode == 'train' else 'test_time render'}), the reference's torch-CPU op "
+                      f"sequence restated (oracle/torch_cpu_ref.py), {r['seconds']:.1f} s after one warm-up step",
+            "best_step_value": r["ray_samples_per_s_best"], "cpu_model": r["cpu_model"],
+            "physical_cores": r["physical_cores"], "nproc": r["nproc"], "allowed_cpus": r["allowed_cpus"],
+            "cgroup_cpu_quota": r["cgroup_cpu_quota"], "thread_calibration_gemm_gflops": r["gemm_gflops"],
+            "torch_parallel_info": r["parallel_info"].strip().replace("\n", "; "),
+            "anchor": "the imported reference itself on 8 threads in the build container: 0.107-0.119 M ray-samples/s "
+                      "training, 0.56-0.69 M inference (BASELINE.md section 2, oracle/torch_cpu_ref.py header)"}
 
 
 def psnr_check(dev):
-    """The metric's '+ PSNR': the reference trained 240 Adam steps on a teacher scene on CPU and its validation-PSNR
-    trajectory is a committed fixture (tools/make_psnr_golden.py -> tests/golden/g15_psnr.npz); the same steps (same
-    images, batches, injected draws, initial weights) run here on the HIP path.  A few seconds; rank 0 at N = 1 only."""
+    """The metric's '+ PSNR': the reference trained on a teacher scene on CPU and its validation-PSNR trajectory is a
+    committed fixture (tools/make_psnr_golden.py -> tests/golden/g15_psnr.npz); the same steps (same images, batches,
+    injected draws, initial weights, learning-rate schedule) run here on the HIP path.  Rank 0 at N = 1 only."""
     import numpy as np
     import torch
     from nerf_siren_amd import Embedding, NeRF, render_rays, synth
     from nerf_siren_amd.training import FusedAdam, FusedMSELoss
-    path = os.path.join(ROOT, "tests", "golden", "g15_psnr.npz")
+    path = os.path.join(ROOT, "tests", "golden", "g19_psnr_long.npz")       # 1 500 steps, 400x400 validation view
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "tests", "golden", "g15_psnr.npz")        # 240 steps, 32x32
     if not os.path.exists(path):
         return None
-    g = np.load(path)
+    g = dict(np.load(path))
     S, F, B = int(g["cfg_S"]), int(g["cfg_F"]), int(g["cfg_batch"])
     steps, every = int(g["cfg_steps"]), int(g["cfg_eval_every"])
+    milestones = [int(v) for v in g["cfg_lr_milestones"]] if "cfg_lr_milestones" in g else []
+    gamma = float(g["cfg_lr_gamma"]) if "cfg_lr_gamma" in g else 1.0
     ms = []
     for seed in (11, 12):
         m = NeRF()
@@ -108,14 +130,20 @@ def psnr_check(dev):
         ms.append(m.to(dev))
     emb = [Embedding(3, 10), Embedding(3, 4)]
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)          # noqa: E731
-    rays, tgt, val_rays, val_tgt = T(g["rays"]), T(g["target"]), T(g["val_rays"]), T(g["val_target"])
+    rays_np, val_np = synth.psnr_rays(g)
+    rays, tgt, val_rays, val_tgt = T(rays_np), T(g["target"]), T(val_np), T(g["val_target"])
     opt, loss_fn = FusedAdam(ms, lr=float(g["cfg_lr"]), eps=1e-8), FusedMSELoss(unit_grad=True)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=milestones, gamma=gamma) if milestones else None
     psnr = []
     for step in range(steps + 1):
         if step % every == 0:
             with torch.no_grad():
-                r = render_rays(ms, emb, val_rays, S, False, 0, 0, F, 1 << 15, True, False)
-            psnr.append(float(-10 * torch.log10(((r["rgb_fine"] - val_tgt) ** 2).mean())))
+                mse, n = 0.0, 0
+                for i in range(0, val_rays.shape[0], 1 << 15):
+                    r = render_rays(ms, emb, val_rays[i:i + (1 << 15)], S, False, 0, 0, F, 1 << 15, True, False)
+                    mse += float(((r["rgb_fine"] - val_tgt[i:i + (1 << 15)]) ** 2).sum())
+                    n += r["rgb_fine"].numel()
+            psnr.append(float(-10 * np.log10(mse / n)))
         if step == steps:
             break
         idx = torch.from_numpy(synth.psnr_batch_indices(step, rays.shape[0], B)).to(dev)
@@ -125,15 +153,124 @@ def psnr_check(dev):
         opt.zero_grad()
         loss.backward()
         opt.step()
+        if sched is not None:
+            sched.step()
     ref = [float(v) for v in g["psnr"]]
     return {"value_db": psnr[-1], "reference_db": ref[-1], "max_abs_diff_db": float(np.abs(np.array(psnr) - ref).max()),
             "trajectory_db": [round(v, 3) for v in psnr], "reference_trajectory_db": [round(v, 3) for v in ref],
-            "protocol": f"teacher scene, {steps} Adam steps of {B} rays ({S}+{F}), validation every {every} steps; "
-                        "reference = /root/reference on CPU (tests/golden/g15_psnr.npz)"}
+            "protocol": f"teacher scene, {steps} Adam steps of {B} rays ({S}+{F})"
+                        + (f", lr x{gamma} at steps {milestones}" if milestones else "")
+                        + f", validation every {every} steps on {val_rays.shape[0]} rays; reference = /root/reference on CPU (tests/golden/" + os.path.basename(path) + ")"}
+
+
+class KernelTimer:
+    """ops profiling hook: HIP events on the launch stream around the field-MLP launches of the fine pass."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.ev = {}
+
+    class _Span:
+        def __init__(self, owner, key):
+            t = owner.torch
+            self.a, self.b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+            self.a.record()
+            owner.ev.setdefault(key, []).append((self.a, self.b))
+
+        def done(self):
+            self.b.record()
+
+    def __call__(self, name, n_per_ray):
+        if n_per_ray != 128:
+            return None
+        return KernelTimer._Span(self, name)
+
+    def clear(self):
+        self.ev.clear()
+
+    def mean_ms(self, name):
+        ev = self.ev.get(name)
+        if not ev:
+            return float("nan")
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+
+def eg3d_bench(dev, steps, warmup):
+    """configs[4]: EG3D tri-plane renderer, planes (1,3,32,256,256), M = 4096 rays x (64+64) samples, forward and
+    forward+backward (gradients to planes and decoder), plus the dense 128^3 = 2 097 152-point run_model query."""
+    import numpy as np
+    import torch
+    from nerf_siren_amd import ImportanceRenderer, OSGDecoder, synth
+    planes = torch.from_numpy(synth.triplanes(1, res=256)).to(dev)
+    dec = OSGDecoder(32, {"decoder_lr_mul": 1.0, "decoder_output_dim": 3})
+    dec.load_state_dict({k: torch.from_numpy(v) for k, v in synth.osg_params(1).items()})
+    dec = dec.to(dev)
+    ren = ImportanceRenderer()
+    opts = dict(synth.EG3D_OPTIONS)
+    M = 4096
+    o, d = synth.eg3d_rays(M, 3)
+    o, d = torch.from_numpy(o[None]).to(dev), torch.from_numpy(d[None]).to(dev)
+
+    def timeit(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def fwd():
+        with torch.no_grad():
+            ren(planes, dec, o, d, opts)
+    t_f = timeit(fwd)
+    pl = planes.clone().requires_grad_(True)
+
+    def fb():
+        pl.grad = None
+        for p_ in dec.parameters():
+            p_.grad = None
+        out = ren(pl, dec, o, d, opts)
+        (out[3].square().mean() + out[4].mean() + out[0].square().mean()).backward()
+    t_fb = timeit(fb)
+    g = np.linspace(-1.5, 1.5, 128, dtype=np.float32)
+    pts = torch.from_numpy(np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(1, -1, 3)).to(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    kms = []
+
+    def dense():
+        with torch.no_grad():
+            a.record()
+            ren.run_model(planes, dec, pts, None, opts)
+            b.record()
+        torch.cuda.synchronize()
+        kms.append(a.elapsed_time(b))
+    for _ in range(warmup):
+        dense()
+    kms.clear()
+    for _ in range(steps):
+        dense()
+    t_d = float(np.mean(kms)) * 1e-3
+    npts = pts.shape[1]
+    gather = npts * (12 + 1536 + 16) / t_d / 1e12            # SURVEY 8d: R 12 B coords + 1 536 B texels / W 16 B per sample
+    return {"workload": "configs[4]: planes (1,3,32,256,256), M=4096 rays x (64+64) samples; dense query 128^3 points",
+            "forward_ms": t_f * 1e3, "forward_samples_per_s": M * 128 / t_f,
+            "forward_backward_ms": t_fb * 1e3, "forward_backward_samples_per_s": M * 128 / t_fb,
+            "dense_query_ms": t_d * 1e3, "dense_points_per_s": npts / t_d,
+            "roofline": {"bound": "hbm", "kernel": "triplane_kernel<1,false> (dense run_model: 12 bilinear taps x 32 ch gathered "
+                         "per point from the 25 MB channels-last plane stack, decoder fused)", "achieved": gather,
+                         "peak": PEAK_HBM, "unit": "TB/s", "frac": gather / PEAK_HBM, "traffic": None,
+                         "bytes_per_launch": npts * (12 + 1536 + 16), "avg_launch_ms": t_d * 1e3,
+                         "note": "algorithmic gather bytes (before cache reuse); the planes are L2/MALL-resident, so this is "
+                                 "a cache-served gather rate priced against the HBM peak"}}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -141,7 +278,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal knobs for a 1-GPU box (never set by the driver): BENCH_BACKEND=gloo BENCH_SHARE_GPU=1 lets two
+    # rehearsal knobs for a 1-GPU box (never set by the driver): BENCH_BACKEND=gloo BENCH_SHARE_GPU=1 lets the
     # ranks share cuda:0 and reduce through gloo, which exercises the same code path as RCCL
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     share = os.environ.get("BENCH_SHARE_GPU", "0") == "1"
@@ -155,111 +292,73 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from nerf_siren_amd import Embedding, NeRF, render_rays, synth
+    import nerf_siren_amd
+    from nerf_siren_amd import Embedding, NeRF, SemanticNeRF, SirenField, render_rays, synth
     from nerf_siren_amd import ops
     from nerf_siren_amd.parallel import FlatGradAllReduce
+    from nerf_siren_amd.training import FusedAdam, FusedMSELoss
 
     B = args.batch
-    if args.math != "fp32":
-        if args.field == "siren" and args.mode != "infer":
-            raise SystemExit("--field siren supports --mode infer only")
-        import nerf_siren_amd
-        nerf_siren_amd.set_math(args.math)
-    models = []
-    siren = args.field == "siren"
-    if siren and args.mode != "infer":
-        raise SystemExit("--field siren supports --mode infer only (the reference never trains its SIREN field)")
-    for seed in (1, 2):
-        if siren:
-            from nerf_siren_amd import SemanticNeRF, SirenField
-            sm = SemanticNeRF()
-            sm.load_state_dict({k: torch.from_numpy(v) for k, v in synth.siren_params(seed).items()})
-            m = SirenField(sm, torch.from_numpy(synth.hash_normal((1, 2304), 10 + seed)),
-                           torch.from_numpy(synth.hash_normal((1, 2304), 20 + seed)))
-        else:
-            m = NeRF()
-            m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
-        models.append(m.to(dev))
+    nerf_siren_amd.set_math(args.math)
     emb = [Embedding(3, 10), Embedding(3, 4)]
     # a pool of batches resident in HBM before the timed region (each rank its own shard of rays)
     n_pool = 8
     rays_pool = [torch.from_numpy(synth.blender_rays(B, seed=1000 * rank + i)).to(dev) for i in range(n_pool)]
     tgt_pool = [torch.from_numpy(synth.hash_uniform((B, 3), 77 + 1000 * rank + i)).to(dev) for i in range(n_pool)]
 
-    train = args.mode == "train"
-    if train:
-        params = [p for m in models for p in m.parameters()]
-        from nerf_siren_amd.training import FusedAdam, FusedMSELoss
+    def make_models(field):
+        ms = []
+        for seed in (1, 2):
+            if field == "siren":
+                sm = SemanticNeRF()
+                sm.load_state_dict({k: torch.from_numpy(v) for k, v in synth.siren_params(seed).items()})
+                m = SirenField(sm, torch.from_numpy(synth.hash_normal((1, 2304), 10 + seed)),
+                               torch.from_numpy(synth.hash_normal((1, 2304), 20 + seed)))
+            else:
+                m = NeRF()
+                m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
+            ms.append(m.to(dev))
+        return ms
+
+    timer = KernelTimer(torch)
+    ops.set_profile_hook(timer)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step, steps, warmup):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize; MAX over ranks."""
+        for i in range(warmup):
+            step(i)
+        barrier()
+        timer.clear()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item())
+
+    def make_step(models, mode):
+        if mode == "infer":
+            def step(i):
+                with torch.no_grad():
+                    render_rays(models, emb, rays_pool[i % n_pool], 64, False, 0, 0, 64, 1024 * 32, True, True)
+            return step
         if args.optimizer == "fused":
             opt = FusedAdam(models, lr=5e-4, eps=1e-8)           # utils/__init__.py:20 (Adam, eps 1e-8), one launch/model
             loss_fn = FusedMSELoss(unit_grad=True)               # losses.py:10-20 + autograd, one launch
         else:
-            opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8)
+            opt = torch.optim.Adam([p for m in models for p in m.param_list()], lr=5e-4, eps=1e-8)
             loss_fn = None
-        reducer = FlatGradAllReduce(models, world)
+        reducer = FlatGradAllReduce(models, world, overlap=not args.no_overlap)
 
-    # ---- per-kernel timing of the dominant kernel (fine MLP forward) -------------------------
-    ev = []
-    orig_fwd = ops.nerf_forward_rays
-
-    def timed_fwd(packed, rays, z, sigma_only=False, save=False):
-        if z.shape[1] != 128:
-            return orig_fwd(packed, rays, z, sigma_only, save)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        out = orig_fwd(packed, rays, z, sigma_only, save)
-        b.record()
-        ev.append((a, b))
-        return out
-
-    import nerf_siren_amd.rendering as R
-    R.ops.nerf_forward_rays = timed_fwd
-    if args.math == "bf16x3":
-        orig_fast = ops.nerf_forward_rays_fast
-
-        def timed_fast(packed, fast, rays, z, sigma_only=False, save=False):
-            if z.shape[1] != 128:
-                return orig_fast(packed, fast, rays, z, sigma_only, save)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            out = orig_fast(packed, fast, rays, z, sigma_only, save)
-            b.record()
-            ev.append((a, b))
-            return out
-
-        ops.nerf_forward_rays_fast = timed_fast
-    if siren:
-        orig_siren = ops.siren_forward_rays
-
-        def timed_siren(packed, rays, z, freq, phase, rpc, sigma_only=False):
-            if z.shape[1] != 128:
-                return orig_siren(packed, rays, z, freq, phase, rpc, sigma_only)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            out = orig_siren(packed, rays, z, freq, phase, rpc, sigma_only)
-            b.record()
-            ev.append((a, b))
-            return out
-
-        ops.siren_forward_rays = timed_siren
-        orig_siren_fast = ops.siren_forward_rays_fast
-
-        def timed_siren_fast(packed, fast, rays, z, freq, phase, rpc, sigma_only=False):
-            if z.shape[1] != 128:
-                return orig_siren_fast(packed, fast, rays, z, freq, phase, rpc, sigma_only)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            out = orig_siren_fast(packed, fast, rays, z, freq, phase, rpc, sigma_only)
-            b.record()
-            ev.append((a, b))
-            return out
-
-        ops.siren_forward_rays_fast = timed_siren_fast
-
-    def step(i):
-        rays = rays_pool[i % n_pool]
-        if train:
-            res = render_rays(models, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, True, False)
+        def step(i):
+            res = render_rays(models, emb, rays_pool[i % n_pool], 64, False, 1.0, 1.0, 64, 1024 * 32, True, False)
             t = tgt_pool[i % n_pool]
             if loss_fn is not None:
                 loss = loss_fn(res, t)
@@ -273,67 +372,87 @@ def main():
             else:
                 reducer.all_reduce()
                 opt.step()
-        else:
-            with torch.no_grad():
-                render_rays(models, emb, rays, 64, False, 0, 0, 64, 1024 * 32, True, True)
+        return step
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    siren = args.field == "siren"
+    train = args.mode == "train"
+    models = make_models(args.field)
+    step = make_step(models, args.mode)
+    dt = timed(step, args.steps, args.warmup)
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    ev.clear()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    if siren:
+        kname = "siren_forward_rays_train" if train else ("siren_forward_rays_fast" if args.math == "bf16x3" else "siren_forward_rays")
+    else:
+        kname = "nerf_forward_rays_fast" if args.math == "bf16x3" else "nerf_forward_rays"
+    kern_ms = timer.mean_ms(kname)
 
     # The same K steps once more on the OPT-IN split-bf16 math (fp32-level accuracy on the bf16 matrix cores, same parity
     # tests) -- reported beside the headline, never as `value`.
     opt_in = None
     if args.math == "fp32" and not siren and not args.no_opt_in:
-        import nerf_siren_amd
         nerf_siren_amd.set_math("bf16x3")
-        for i in range(args.warmup):
-            step(i)
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        barrier()
-        dt2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(dt2, op=dist.ReduceOp.MAX)
+        dt2 = timed(step, args.steps, args.warmup)
         nerf_siren_amd.set_math("fp32")
-        dt2 = float(dt2.item())
         opt_in = {"math": "bf16x3 (exact 3-way bf16 split of both operands, 6 bf16 MFMA per product, fp32 accumulate)",
                   "value": world * B * 192 * args.steps / dt2, "unit": "ray-samples/s", "ms_per_step": dt2 / args.steps * 1e3}
+
     # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc summary (tools/pmc_summary.py);
     # counters cannot be collected from inside the timed run
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        want = ("siren_forward_kernel<true, false>" if siren else
-                ("nerf_forward_kernel<false, false, true>" if train else "nerf_forward_kernel<false, false, false>"))
-        for k, e in pmc.items():
-            if want in k and "hbm_bytes" in e and B == 1024:
-                traffic = e["hbm_bytes"]
-    except Exception:
-        pass
+    def pmc_traffic(want):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            for k, e in pmc.items():
+                if want in k and "hbm_bytes" in e and B == 1024:
+                    return e["hbm_bytes"]
+        except Exception:
+            pass
+        return None
+    if siren:
+        traffic = pmc_traffic("siren_forward_kernel<true, false, true>" if train else "siren_forward_kernel<true, false, false>")
+    else:
+        traffic = pmc_traffic("nerf_forward_kernel<false, false, true>" if train else "nerf_forward_kernel<false, false, false>")
     flops_per_launch = B * 128 * (FLOP_SIREN if siren else FLOP_FULL)
     achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
     # exact fp32 MFMA: 157.3 TF dense; split-bf16 (six bf16 MFMAs per fp32-equivalent product): 2500/6
     peak = PEAK_F32_MFMA if args.math == "fp32" else 2500.0 / 6.0
+
+    extra = {}
+    if world == 1 and not args.no_extra and args.math == "fp32":
+        ks, kw = max(5, args.steps // 2), max(2, args.warmup // 2)
+        if not siren:
+            # the same field at test time (eval.py:85-96)
+            st = make_step(models, "infer") if train else make_step(make_models("nerf"), "train")
+            d2 = timed(st, ks, kw)
+            k2 = timer.mean_ms("nerf_forward_rays")
+            extra["infer" if train else "train"] = {
+                "ms_per_step": d2 / ks * 1e3, "value": B * 192 * ks / d2, "unit": "ray-samples/s",
+                "roofline": {"bound": "mfma", "kernel": "nerf_forward_kernel (fine MLP, 128 samples/ray)",
+                             "achieved": B * 128 * FLOP_FULL / (k2 * 1e-3) / 1e12, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                             "frac": B * 128 * FLOP_FULL / (k2 * 1e-3) / 1e12 / PEAK_F32_MFMA, "avg_launch_ms": k2}}
+            # the FiLM-SIREN field of configs[1] (models/nerf.py:142-216) behind the same render_rays: training + inference
+            sm = make_models("siren")
+            d_t = timed(make_step(sm, "train"), ks, kw)
+            k_t = timer.mean_ms("siren_forward_rays_train")
+            d_i = timed(make_step(sm, "infer"), ks, kw)
+            k_i = timer.mean_ms("siren_forward_rays")
+            fl = B * 128 * FLOP_SIREN
+            extra["siren"] = {
+                "workload": f"configs[1] with the FiLM-SIREN field (9 FiLM layers x 256, 529 156 parameters) coarse+fine, "
+                            f"batch_size={B}",
+                "train_ms_per_step": d_t / ks * 1e3, "train_value": B * 192 * ks / d_t,
+                "infer_ms_per_step": d_i / ks * 1e3, "infer_value": B * 192 * ks / d_i, "unit": "ray-samples/s",
+                "roofline": {"bound": "mfma", "kernel": "siren_forward_kernel<true,false,false> (fine pass, 128 samples/ray, "
+                             "inference)", "achieved": fl / (k_i * 1e-3) / 1e12, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                             "frac": fl / (k_i * 1e-3) / 1e12 / PEAK_F32_MFMA, "flops_per_launch": fl, "avg_launch_ms": k_i,
+                             "traffic": pmc_traffic("siren_forward_kernel<true, false, false>")},
+                "roofline_train_forward": {"bound": "mfma", "kernel": "siren_forward_kernel<true,false,true> (fine pass, saves "
+                                           "activations)", "achieved": fl / (k_t * 1e-3) / 1e12, "peak": PEAK_F32_MFMA,
+                                           "unit": "TFLOP/s", "frac": fl / (k_t * 1e-3) / 1e12 / PEAK_F32_MFMA,
+                                           "avg_launch_ms": k_t,
+                                           "traffic": pmc_traffic("siren_forward_kernel<true, false, true>")}}
+            del sm
+        ops.set_profile_hook(None)
+        extra["eg3d"] = eg3d_bench(dev, ks, kw)
 
     if rank == 0:
         total_samples = world * B * 192 * args.steps
@@ -347,15 +466,17 @@ def main():
                                    f"batch_size={B} rays/GPU, {'FiLM-SIREN 9x256' if siren else 'NeRF 8x256'} coarse+fine, "
                                    f"mode={args.mode}",
                        "rays_per_gpu": B, "samples_per_ray": 192, "mode": args.mode,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
+                       "parallelism": (f"dp{world}, one rank per GPU, {'fine-model all-reduce overlapped with the coarse backward' if not args.no_overlap else 'one joint all-reduce'}"
+                                       if world > 1 else "single")},
             "rays_per_s": world * B * args.steps / dt,
             "roofline": {"bound": "mfma", "kernel": ("siren_forward_kernel" if siren else ("nerf_forward_kernel" if args.math == "fp32" else
                                                                           "nerf_forward_bf16x3_kernel"))
-                                   + " (fine MLP, 128 samples/ray)",
+                                   + " (fine MLP, 128 samples/ray" + (", saves activations)" if train else ")"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": kern_ms},
         }
+        out.update(extra)
         if opt_in is not None:
             out["opt_in"] = opt_in
         if world == 1 and train and not siren and not args.no_psnr:

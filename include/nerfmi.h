@@ -97,6 +97,10 @@ int nerfmi_nerf_forward_embedded(const float *packed, const float *x, int64_t n,
  * DEVICE pointers, same order/shapes as `params`; gradients are WRITTEN (not
  * accumulated).  workspace: nerfmi_nerf_backward_workspace_floats(n_points). */
 size_t nerfmi_nerf_backward_workspace_floats(int64_t n_points);
+/* NeRF.forward(x) (nerf.py:83-124) on pre-embedded rows x (n, 90) with the activations saved, for training through the
+ * module-level API: back-propagate with nerfmi_nerf_backward_rays(packed, NULL, NULL, n, 1, saved, grad_out, ...). */
+int nerfmi_nerf_forward_embedded_train(const float *packed, const float *x, int64_t n, float *out, float *saved,
+                                       nerfmi_stream_t stream);
 int nerfmi_nerf_backward_rays(const float *packed, const float *rays, const float *z, int n_rays, int n_per_ray,
                               const float *saved, const float *grad_out, float *const *grad_params,
                               float *workspace, nerfmi_stream_t stream);
@@ -216,6 +220,12 @@ int nerfmi_ndc_rays(int H, int W, double focal, double near, const float *rays_o
  * image in order (then n_rays = n_images*H*W).  rays_out (n_rays, 8). */
 int nerfmi_generate_rays(const float *c2w, int n_images, int H, int W, double focal, const int64_t *pixel_index,
                          int64_t n_rays, int ndc, double near, double far, float *rays_out, nerfmi_stream_t stream);
+
+/* The N^3 sample grid of the EG3D dense query ("neural volume", BASELINE configs[4]):
+ * extract_color_mesh_eg3d.py:72-94 create_samples, op by op in fp32.  origin_* = voxel_origin - cube_length/2
+ * (the reference's `voxel_origin` after :74), voxel_size = cube_length/(N-1); samples_out (N^3, 3). */
+int nerfmi_create_samples(int N, double origin_x, double origin_y, double origin_z, double voxel_size, float *samples_out,
+                          nerfmi_stream_t stream);
 
 /* ==== the step after the path in training ===========================================
  * losses.py:10-20 MSELoss = nn.MSELoss(mean)(rgb_coarse, t) [+ nn.MSELoss(mean)(rgb_fine, t)], its autograd

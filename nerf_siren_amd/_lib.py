@@ -29,6 +29,7 @@ SIGNATURES = {
     "nerfmi_nerf_backward_rays_fast": (_i, [_f, _f, _i, _i, _f, _f, C.POINTER(C.c_void_p), _f, _f]),
     "nerfmi_nerf_forward_rays_fast": (_i, [_f, _f, _f, _f, _i, _i, _i, _f, _f, _f]),
     "nerfmi_nerf_forward_embedded": (_i, [_f, _f, _i64, _i, _f, _f]),
+    "nerfmi_nerf_forward_embedded_train": (_i, [_f, _f, _i64, _f, _f, _f]),
     "nerfmi_nerf_backward_workspace_floats": (C.c_size_t, [_i64]),
     "nerfmi_nerf_backward_rays": (_i, [_f, _f, _f, _i, _i, _f, _f, C.POINTER(C.c_void_p), _f, _f]),
     "nerfmi_siren_packed_floats": (C.c_size_t, []),
@@ -73,6 +74,7 @@ SIGNATURES = {
     "nerfmi_get_rays": (_i, [_f, _f, _i64, _f, _f, _f]),
     "nerfmi_ndc_rays": (_i, [_i, _i, C.c_double, C.c_double, _f, _f, _i64, _f, _f, _f]),
     "nerfmi_generate_rays": (_i, [_f, _i, _i, _i, C.c_double, _f, _i64, _i, C.c_double, C.c_double, _f, _f]),
+    "nerfmi_create_samples": (_i, [_i, C.c_double, C.c_double, C.c_double, C.c_double, _f, _f]),
     "nerfmi_mse_loss": (_i, [_f, _f, _f, _i64, _fl, _f, _f, _f, _f]),
     "nerfmi_adam_step": (_i, [_f, _f, _f, _f, _i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64,
                              C.c_double, _f]),

@@ -9,7 +9,9 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "lib", "libnerfmi.so")
+# experiment builds (tools/exp_*.py): NERFMI_LIB_OUT=<path> writes another library, NERFMI_SOURCES="a.hip b.hip" restricts
+# the translation units, NERFMI_EXTRA_FLAGS="-D..." adds switches (objects of a different flag set get their own directory)
+LIB = os.environ.get("NERFMI_LIB_OUT") or os.path.join(HERE, "lib", "libnerfmi.so")
 SOURCES = ["rays.hip", "mlp.hip", "mlp_bwd.hip", "siren.hip", "siren_bwd.hip", "eg3d.hip", "eg3d_bwd.hip", "mlp_bf16x3.hip", "train_step.hip", "raygen.hip"]
 # -ffp-contract=off: the per-ray kernels reproduce torch's op-by-op fp32 rounding
 # (oracle/nerf_oracle.py); fused multiply-adds are written explicitly where wanted.
@@ -59,7 +61,8 @@ def _objdir():
 
 
 def _jobs():
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    names = os.environ.get("NERFMI_SOURCES", "").split() or SOURCES
+    srcs = [os.path.join(CSRC, s) for s in names]
     missing = [s for s in srcs if not os.path.exists(s)]
     if missing:
         raise RuntimeError(f"missing sources: {missing}")

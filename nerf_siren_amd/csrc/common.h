@@ -27,6 +27,20 @@ inline int check_launch(const char *what) {
     return NERFMI_OK;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's instance of the kernel, so "done" is
+// tracked per device (a per-thread flag would skip the call on a second GPU driven from the same thread).  Racing
+// threads at worst both set the same value.
+struct PerDeviceOnce {
+    bool done[64] = {};
+    // true if the caller must (re)do the per-device setup now
+    bool needed(int &dev) {
+        dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; return true; }
+        return dev < 0 || dev >= 64 || !done[dev];
+    }
+    void mark(int dev) { if (dev >= 0 && dev < 64) done[dev] = true; }
+};
+
 constexpr int WAVE = 64;
 
 // torch.linspace(0,1,n)[i] on CPU fp32: symmetric fill with one rounding

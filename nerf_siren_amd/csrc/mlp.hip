@@ -202,10 +202,16 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
     unsigned mk[4] = {0u, 0u, 0u, 0u};
     auto relu_epi = [&](int row0) {
         return [&S, &mk, row0](int jb, int q, f32x4 c, int) {
+#ifndef NERFMI_EXP_NOEPI
             c = relu4(c);
+#endif
             if (SAVE) {
+#ifndef NERFMI_EXP_NOMASK
                 mask_or(mk, jb, q, c);
+#endif
+#ifndef NERFMI_EXP_NOSTORE
                 store_slice(S, row0 + 32 * jb, q, c);
+#endif
             }
             return c;
         };
@@ -336,6 +342,18 @@ int nerfmi_nerf_forward_embedded(const float *packed, const float *x, int64_t n,
         hipLaunchKernelGGL((nerf_forward_kernel<true, false, false>), grid, block, 0, st, packed, nullptr, nullptr, x,
                            n, 1, out, nullptr, (int64_t)0);
     return check_launch("nerf_forward_embedded");
+}
+
+// NeRF.forward(x) on pre-embedded rows with the activations saved for nerfmi_nerf_backward_rays(n_rays = n, n_per_ray = 1)
+int nerfmi_nerf_forward_embedded_train(const float *packed, const float *x, int64_t n, float *out, float *saved,
+                                       nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n >= 0, "nerf_forward_embedded_train: bad size");
+    if (n == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(packed && x && out && saved, "nerf_forward_embedded_train: null pointer");
+    const int64_t waves = (n + 31) / 32;
+    hipLaunchKernelGGL((nerf_forward_kernel<true, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, packed, nullptr, nullptr, x, n, 1, out, saved, pad_points(n));
+    return check_launch("nerf_forward_embedded_train");
 }
 
 }  // extern "C"

@@ -253,15 +253,16 @@ int nerfmi_nerf_forward_rays_fast(const float *packed, const void *fast, const f
     const void *kernels[3] = {reinterpret_cast<const void *>(nerf_forward_bf16x3_kernel<false, false>),
                               reinterpret_cast<const void *>(nerf_forward_bf16x3_kernel<true, false>),
                               reinterpret_cast<const void *>(nerf_forward_bf16x3_kernel<false, true>)};
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    int attr_dev;
+    if (attr_set.needed(attr_dev)) {
         for (const void *k : kernels)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess) {
                 (void)hipGetLastError();
                 set_error("nerf_forward_rays_fast: cannot raise the dynamic LDS limit");
                 return NERFMI_E_LAUNCH;
             }
-        attr_set = true;
+        attr_set.mark(attr_dev);
     }
     const int64_t waves = (n_points + 31) / 32;
     const int64_t ld = waves * 32;

@@ -537,8 +537,9 @@ static int backward_impl(const char *who, const float *packed, const void *fast,
     const DwPlan P = make_plan(ld, fast != nullptr);
     const size_t lds = sizeof(float) * 2 * 512 * LROW;  // two 73 728-B tile buffers (> the 64 KiB default dynamic-LDS limit)
     static_assert(2 * DWF_KSTEP_BYTES <= sizeof(float) * 2 * 512 * LROW, "the split-bf16 k-step buffers fit in the same allocation");
-    static thread_local bool lds_attr_set = false;
-    if (!lds_attr_set) {
+    static PerDeviceOnce lds_attr_set;
+    int attr_dev;
+    if (lds_attr_set.needed(attr_dev)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(nerf_dw_bf16x3_kernel),
@@ -549,7 +550,7 @@ static int backward_impl(const char *who, const float *packed, const void *fast,
             set_error("%s: cannot raise the dynamic LDS limit", who);
             return NERFMI_E_LAUNCH;
         }
-        lds_attr_set = true;
+        lds_attr_set.mark(attr_dev);
     }
     if (fast)
         hipLaunchKernelGGL(nerf_backward_chain_bf16x3_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), FLDS_BYTES, st,

@@ -128,7 +128,11 @@ __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, 
     for (int jb = 0; jb < JB; ++jb) {
         auto pv = (jb == 0) ? pv_prev : pre(jb);
         f32x16 c;
+#ifdef NERFMI_EXP_NOBIAS
+        if (false) {
+#else
         if (bias) {
+#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 b = ldg4(bias + 32 * jb + 8 * q);
@@ -153,7 +157,9 @@ __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, 
                     *reinterpret_cast<f32x4 *>(ldst + (((stage + 1 + PH) % NSLOT) * GS + gl) * 256) = ws.st[gl];
                     ws.st[gl] = ldg4(gsrc + ((stage + 2) * GS + gl) * 256);
                 }
+#ifndef NERFMI_EXP_NOBARRIER
                 if (gl == GS / 2) __syncthreads();
+#endif
                 // fragments are read ONE group ahead (two register sets): the LDS latency of group g+1 hides
                 // behind group g's four MFMAs instead of draining the pipe in front of every group
                 const f32x4 a = (g == 0) ? lread(0) : a_next;
@@ -218,7 +224,11 @@ __device__ __forceinline__ void store_slice(const RowImage &im, int row0, int q,
     // the L2-resident weights.
     float *dst = im.tile + (row0 + 8 * q + 4 * (im.lane >> 5)) * 32 + (im.lane & 31);
 #pragma unroll
+#ifdef NERFMI_EXP_TSTORE
+    for (int t = 0; t < 4; ++t) dst[32 * t] = v[t];
+#else
     for (int t = 0; t < 4; ++t) __builtin_nontemporal_store(v[t], dst + 32 * t);
+#endif
 }
 __device__ __forceinline__ void store_block(const RowImage &im, int row0, const f32x16 &v) {
 #pragma unroll

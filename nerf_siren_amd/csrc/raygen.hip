@@ -117,6 +117,25 @@ static NdcConst ndc_const(int H, int W, double focal, double near) {
     return K;
 }
 
+// create_samples of extract_color_mesh_eg3d.py:72-94 (the N^3 query grid of the EG3D "neural volume"), op by op in
+// fp32 as the torch CPU ops run it: column 2 = idx % N; column 1 = (float(idx) / N) % N; column 0 =
+// ((float(idx) / N) / N) % N -- FLOAT divisions, so columns 1 and 0 are not integer voxel indices (restated as is) --
+// then  s * voxel_size + origin  per column (origin index reversed, :88-90).  Correctly rounded divisions: torch's
+// device division by a scalar multiplies by the reciprocal, which moves these values by up to 10 ulp.
+__global__ void create_samples_kernel(int N, int64_t n_points, float voxel_size, float o0, float o1, float o2,
+                                      float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_points) return;
+    const float fN = (float)N;
+    const float q = __fdiv_rn((float)i, fN);
+    const float s2 = (float)(i % N);
+    const float s1 = fmodf(q, fN);
+    const float s0 = fmodf(__fdiv_rn(q, fN), fN);
+    out[3 * i + 0] = __fadd_rn(__fmul_rn(s0, voxel_size), o2);
+    out[3 * i + 1] = __fadd_rn(__fmul_rn(s1, voxel_size), o1);
+    out[3 * i + 2] = __fadd_rn(__fmul_rn(s2, voxel_size), o0);
+}
+
 }  // namespace nerfmi
 
 using namespace nerfmi;
@@ -165,6 +184,16 @@ int nerfmi_generate_rays(const float *c2w, int n_images, int H, int W, double fo
                        n_images, H, W, (float)(W / 2.0), (float)(H / 2.0), (float)focal, pixel_index, n_rays, ndc, K,
                        ndc ? 0.0f : (float)near, ndc ? 1.0f : (float)far, rays_out);
     return check_launch("generate_rays");
+}
+
+int nerfmi_create_samples(int N, double origin_x, double origin_y, double origin_z, double voxel_size, float *samples_out,
+                          nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(N >= 2 && N <= 1024, "create_samples: 2 <= N <= 1024 required");
+    NERFMI_REQUIRE(samples_out, "create_samples: null pointer");
+    const int64_t n = (int64_t)N * N * N;
+    hipLaunchKernelGGL(create_samples_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, n,
+                       (float)voxel_size, (float)origin_x, (float)origin_y, (float)origin_z, samples_out);
+    return check_launch("create_samples");
 }
 
 }  // extern "C"

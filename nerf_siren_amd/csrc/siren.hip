@@ -230,8 +230,9 @@ int nerfmi_siren_forward_rays_fast(const float *packed, const void *fast, const 
     const int64_t n_points = (int64_t)n_rays * n_per_ray;
     if (n_points == 0) return NERFMI_OK;
     NERFMI_REQUIRE(packed && fast && rays && z && frequencies && phase_shifts && out, "siren_forward_rays_fast: null pointer");
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    int attr_dev;
+    if (attr_set.needed(attr_dev)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(siren_forward_bf16x3_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(siren_forward_bf16x3_kernel<true>),
@@ -240,7 +241,7 @@ int nerfmi_siren_forward_rays_fast(const float *packed, const void *fast, const 
             set_error("siren_forward_rays_fast: cannot raise the dynamic LDS limit");
             return NERFMI_E_LAUNCH;
         }
-        attr_set = true;
+        attr_set.mark(attr_dev);
     }
     const int64_t waves = (n_points + 31) / 32;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);

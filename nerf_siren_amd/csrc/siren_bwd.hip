@@ -249,17 +249,16 @@ int nerfmi_siren_backward(const float *packed, const float *saved, const float *
     const int64_t waves = (n_points + 31) / 32;
     const DwPlan P = siren_plan(ld);
     const size_t lds = sizeof(float) * 2 * 512 * LROW;  // two 73 728-B tile buffers (> the 64 KiB default dynamic-LDS limit)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static bool attr_set[64] = {};                      // per device: the attribute lives with the device's code object
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    static PerDeviceOnce attr_set;
+    int attr_dev;
+    if (attr_set.needed(attr_dev)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(siren_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             set_error("siren_backward: cannot raise the dynamic LDS limit");
             return NERFMI_E_LAUNCH;
         }
-        attr_set[dev] = true;
+        attr_set.mark(attr_dev);
     }
     hipLaunchKernelGGL(siren_backward_chain_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
                        grad_out, frequencies, n_points, points_per_cond, ld, work);

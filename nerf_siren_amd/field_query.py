@@ -8,6 +8,9 @@
     sigma_grid    the N^3 occupancy grid of extract_color_mesh.py:117-140 (np.meshgrid 'xy' ordering, zero
                   directions, sigma clamped at 0)
     pack_vol      the sparse `.vol` records of extract_mesh.ipynb cell 7 (uint32 pairs [voxel index, r<<24|g<<16|b<<8|a])
+    create_samples / eg3d_sigma_grid
+                  the EG3D "neural volume" of BASELINE configs[4]: the N^3 sample grid of
+                  extract_color_mesh_eg3d.py:72-94 and the slab-wise run_model query + flip of :177-195
 
 marching cubes / mesh colouring (PyMCubes, open3d) stay on the host and out of scope.
 """
@@ -71,3 +74,27 @@ def pack_vol(rgbsigma, N, extent) -> np.ndarray:
     s = (rgb[:, 0] << 24) + (rgb[:, 1] << 16) + (rgb[:, 2] << 8) + (a[idx] * 255).to(torch.int64)
     res = torch.stack([idx, s], -1).reshape(-1)
     return (res & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)
+
+
+def create_samples(N=256, voxel_origin=(0, 0, 0), cube_length=2.0, device=None):
+    """extract_color_mesh_eg3d.py:72-94 on the device -> (samples (1, N^3, 3), voxel_origin (3,) float64 numpy,
+    voxel_size).  As in the reference the y and x columns come from FLOAT divisions of the flat index
+    ((idx.float() / N) % N, ((idx.float() / N) / N) % N), not from integer voxel indices."""
+    origin = np.array(voxel_origin, np.float64) - cube_length / 2
+    voxel_size = cube_length / (N - 1)
+    s = torch.empty((N ** 3, 3), device=device, dtype=torch.float32)
+    ops.check(ops._lib.lib().nerfmi_create_samples(int(N), float(origin[0]), float(origin[1]), float(origin[2]),
+                                                   float(voxel_size), ops.ptr(s), ops._stream(s)), "create_samples")
+    return s.unsqueeze(0), origin, voxel_size
+
+
+def eg3d_sigma_grid(renderer, planes, decoder, options, N=256, cube_length=3.0, max_batch=1000000):
+    """The query loop of extract_color_mesh_eg3d.py:177-195: create_samples(N, [0,0,0], cube_length) -> run_model in
+    slabs of max_batch points -> sigma reshaped (N,N,N) and flipped along axis 0.  planes (1,3,32,H,W)."""
+    samples, _, _ = create_samples(N, (0, 0, 0), cube_length, device=planes.device)
+    sigmas = torch.empty((1, samples.shape[1], 1), device=planes.device)
+    with torch.no_grad():
+        for head in range(0, samples.shape[1], max_batch):
+            sigmas[:, head:head + max_batch] = renderer.run_model(planes, decoder, samples[:, head:head + max_batch], None,
+                                                                  options)['sigma']
+    return torch.flip(sigmas.reshape(N, N, N), (0,))

@@ -96,9 +96,13 @@ class NeRF(nn.Module):
         return self._fast
 
     def forward(self, x, sigma_only=False):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            from .rendering import EmbeddedField
-            return EmbeddedField.apply(self, x, bool(sigma_only), *self.param_list())
+        if torch.is_grad_enabled():
+            if x.requires_grad:
+                raise NotImplementedError("gradients w.r.t. the embedded inputs are not implemented (the embeddings have "
+                                          "no parameters; the reference's training path never needs them)")
+            if any(p.requires_grad for p in self.parameters()):
+                from .rendering import EmbeddedField
+                return EmbeddedField.apply(self, x, bool(sigma_only), *self.param_list())
         return ops.nerf_forward_embedded(self.packed(), x, sigma_only)
 
 

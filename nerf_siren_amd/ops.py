@@ -178,6 +178,30 @@ def nerf_forward_embedded(packed, x, sigma_only=False):
     return out
 
 
+def nerf_forward_embedded_train(packed, x):
+    """Training forward of NeRF.forward(x) on pre-embedded rows x (B, 90) -> (out (B,4), saved)."""
+    x = _req(x, "x", (None, 90))
+    packed = _req(packed, "packed", (_lib.lib().nerfmi_nerf_packed_floats(),))
+    n = x.shape[0]
+    out = torch.empty((n, 4), device=x.device, dtype=torch.float32)
+    saved = torch.empty(nerf_saved_floats(n), device=x.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_nerf_forward_embedded_train(ptr(packed), ptr(x), n, ptr(out), ptr(saved), _stream(x)),
+          "nerf_forward_embedded_train")
+    return out, saved
+
+
+def nerf_backward_points(packed, saved, grad_out, grads=None):
+    """Backward of nerf_forward_embedded_train: grad_out (B,4) -> the 24 gradients (the inputs carry none)."""
+    grad_out = _req(grad_out, "grad_out", (None, 4))
+    n = grad_out.shape[0]
+    if grads is None:
+        grads = flat_views(torch.empty(PARAM_NUMEL, device=grad_out.device, dtype=torch.float32))
+    ws = torch.empty(_lib.lib().nerfmi_nerf_backward_workspace_floats(n), device=grad_out.device, dtype=torch.float32)
+    check(_lib.lib().nerfmi_nerf_backward_rays(ptr(packed), None, None, n, 1, ptr(saved), ptr(grad_out), _ptr_array(grads),
+                                               ptr(ws), _stream(grad_out)), "nerf_backward_rays")
+    return grads
+
+
 def nerf_backward_rays(packed, rays, z, saved, grad_out, grads=None, fast=None):
     """-> list of 24 gradient tensors (PARAM_ORDER), written not accumulated.
     fast: the split-bf16 image (nerf_pack_fast) to run the dX chain on the bf16 matrix cores (opt-in math)."""

@@ -151,13 +151,29 @@ class SirenPoints(torch.autograd.Function):
 
 
 class EmbeddedField(torch.autograd.Function):
-    """NeRF.forward(x, sigma_only) with autograd (module-level API)."""
+    """NeRF.forward(x, sigma_only) (models/nerf.py:83-124) with autograd w.r.t. the 24 parameters: the module-level API
+    on pre-embedded rows.  sigma_only runs the same saved forward with a zero direction embedding and back-propagates
+    [0, 0, 0, d sigma]: the gradients of the colour branch come out as exact zeros (the reference leaves them None)."""
 
     @staticmethod
     def forward(ctx, model, x, sigma_only, *params):
-        raise NotImplementedError("training through NeRF.forward(x) on pre-embedded inputs is not wired yet; "
-                                  "train through render_rays() (the reference's only training path, "
-                                  "system.py:199-223) or call under torch.no_grad()")
+        packed = model.packed()
+        if sigma_only:
+            x = torch.cat([x, x.new_zeros((x.shape[0], 27))], 1)
+        out, saved = ops.nerf_forward_embedded_train(packed, x.contiguous())
+        ctx.save_for_backward(saved, packed)
+        ctx.model, ctx.sigma_only = model, bool(sigma_only)
+        return out[:, 3:4].contiguous() if sigma_only else out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        saved, packed = ctx.saved_tensors
+        if ctx.sigma_only:
+            g_out = torch.cat([g_out.new_zeros((g_out.shape[0], 3)), g_out], 1)
+        out = _claim_grad_target(ctx.model, g_out.device)
+        grads = ops.nerf_backward_points(packed, saved, g_out.contiguous(), grads=out)
+        _grad_ready(ctx.model, out)
+        return (None, None, None, *grads)
 
 
 def _rng(rng, key, shape, device, kind):

@@ -201,6 +201,28 @@ def eg3d_rays(n_rays: int, seed: int = 0, radius: float = 2.7):
 # ---------------------------------------------------------------------------
 # PSNR-parity protocol (tools/make_psnr_golden.py <-> tests): deterministic batches and random draws
 # ---------------------------------------------------------------------------
+def view_rays(res: int, view_seed: int) -> np.ndarray:
+    """All res*res rays (res*res, 8) of one lego-like camera (same geometry as blender_rays), row-major pixels."""
+    uv = hash_uniform((1, 2), view_seed * 7919 + 11)
+    c2w = _look_at_c2w(float(uv[0, 0]) * np.deg2rad(60.0), float(uv[0, 1]) * 2 * np.pi, LEGO_RADIUS)
+    focal = np.float32(0.5 * res / np.tan(0.5 * LEGO_ANGLE_X))
+    j, i = np.meshgrid(np.arange(res, dtype=np.float32), np.arange(res, dtype=np.float32), indexing="ij")
+    dirs = np.stack([(i - res / 2) / focal, -(j - res / 2) / focal, -np.ones_like(i)], -1).reshape(-1, 3).astype(np.float32)
+    d = (dirs @ c2w[:, :3].T).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    o = np.broadcast_to(c2w[:, 3], d.shape)
+    nf = np.tile(np.array([[2.0, 6.0]], np.float32), (d.shape[0], 1))
+    return np.concatenate([o, d, nf], -1).astype(np.float32)
+
+
+def psnr_rays(g) -> tuple:
+    """(train rays, validation rays) of a PSNR fixture: stored (g15) or regenerated from the view seeds (g19)."""
+    if "rays" in g:
+        return g["rays"], g["val_rays"]
+    rays = np.concatenate([view_rays(int(g["cfg_res"]), 300 + v) for v in range(int(g["cfg_n_train_views"]))], 0)
+    return rays, view_rays(int(g["cfg_val_res"]), 399)
+
+
 def psnr_batch_indices(step: int, n_total: int, batch: int) -> np.ndarray:
     return np.minimum((hash_uniform((batch,), 80000 + step) * n_total).astype(np.int64), n_total - 1)
 

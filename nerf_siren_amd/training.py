@@ -85,12 +85,11 @@ class FusedAdam(torch.optim.Optimizer):
                     offs.append(off)
                     off += k
             self._entries.append(dict(model=m, params=ps, offsets=offs, flat=flat, exp_avg=torch.zeros_like(flat),
-                                      exp_avg_sq=torch.zeros_like(flat), scratch=None))
+                                      exp_avg_sq=torch.zeros_like(flat), scratch=None, step=0))
             params += ps
             if hasattr(m, "mark_parameters_changed"):
                 m.mark_parameters_changed()
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._n_steps = 0
 
     def _flat_grad(self, e):
         ps = e["params"]
@@ -112,7 +111,7 @@ class FusedAdam(torch.optim.Optimizer):
     # checkpoint / resume: the moments live in flat buffers outside torch's per-parameter state
     def state_dict(self):
         sd = super().state_dict()
-        sd["fused"] = {"n_steps": self._n_steps,
+        sd["fused"] = {"steps": [e["step"] for e in self._entries],
                        "exp_avg": [e["exp_avg"].clone() for e in self._entries],
                        "exp_avg_sq": [e["exp_avg_sq"].clone() for e in self._entries]}
         return sd
@@ -133,7 +132,9 @@ class FusedAdam(torch.optim.Optimizer):
             for e, m, v in zip(self._entries, fused["exp_avg"], fused["exp_avg_sq"]):
                 e["exp_avg"].copy_(m.to(e["exp_avg"].device))
                 e["exp_avg_sq"].copy_(v.to(e["exp_avg_sq"].device))
-        self._n_steps = int(fused["n_steps"])
+        steps = fused["steps"] if "steps" in fused else [int(fused["n_steps"])] * len(self._entries)
+        for e, n in zip(self._entries, steps):
+            e["step"] = int(n)
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
@@ -142,12 +143,12 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         g = self.param_groups[0]
-        self._n_steps += 1
         for e in self._entries:
             gflat = self._flat_grad(e)
             if gflat is None:
-                continue
-            ops.adam_step(e["flat"], gflat, e["exp_avg"], e["exp_avg_sq"], self._n_steps, g["lr"], g["betas"], g["eps"],
+                continue                                # no gradient this step: torch.optim.Adam skips the parameter too,
+            e["step"] += 1                              # and its bias correction counts only the steps it took
+            ops.adam_step(e["flat"], gflat, e["exp_avg"], e["exp_avg_sq"], e["step"], g["lr"], g["betas"], g["eps"],
                           g["weight_decay"], grad_scale)
             if hasattr(e["model"], "mark_parameters_changed"):
                 e["model"].mark_parameters_changed()

@@ -593,6 +593,26 @@ def grid_points(N, x_range, y_range, z_range):
     return np.stack(np.meshgrid(x, y, z), -1).reshape(-1, 3).astype(F32)
 
 
+def create_samples(N=256, voxel_origin=(0, 0, 0), cube_length=2.0):
+    """extract_color_mesh_eg3d.py:72-94 (the DeepSDF grid helper as this fork runs it).  NB the y and x columns are
+    built with FLOAT division -- (idx.float() / N) % N, ((idx.float() / N) / N) % N -- so they are not integer voxel
+    indices but vary continuously with the flat index; restated as is (fp32 arithmetic of the torch ops).
+    Returns samples (1, N^3, 3) with columns scaled as in :88-90, voxel_origin (3,) float64, voxel_size."""
+    origin = np.array(voxel_origin, F64) - cube_length / 2
+    voxel_size = cube_length / (N - 1)
+    idx = np.arange(N ** 3, dtype=np.int64)
+    fN = F32(N)
+    s = np.zeros((N ** 3, 3), F32)
+    s[:, 2] = (idx % N).astype(F32)
+    q = (idx.astype(F32) / fN).astype(F32)
+    s[:, 1] = np.fmod(q, fN)
+    s[:, 0] = np.fmod((q / fN).astype(F32), fN)
+    s[:, 0] = (s[:, 0] * F32(voxel_size)).astype(F32) + F32(origin[2])
+    s[:, 1] = (s[:, 1] * F32(voxel_size)).astype(F32) + F32(origin[1])
+    s[:, 2] = (s[:, 2] * F32(voxel_size)).astype(F32) + F32(origin[0])
+    return s[None], origin, voxel_size
+
+
 def query_field(p: dict, xyz, dirs=None, sigma_only=False):
     xyz = np.asarray(xyz, F32).reshape(-1, 3)
     dirs = np.zeros_like(xyz) if dirs is None else np.asarray(dirs, F32).reshape(-1, 3)

@@ -174,10 +174,59 @@ def host_info() -> dict:
         allowed = os.cpu_count() or 1
     logical = logical or (os.cpu_count() or 1)
     physical = len(pairs) or logical
-    # threads that can actually run in parallel here: physical cores, capped by the CPUs this process is allowed on
-    smt = max(1, logical // physical)
-    usable = max(1, min(physical, allowed // smt if allowed >= smt else allowed))
-    return {"cpu_model": model, "physical_cores": physical, "nproc": logical, "allowed_cpus": allowed, "threads": usable}
+    quota = cgroup_cpu_quota()
+    return {"cpu_model": model, "physical_cores": physical, "nproc": logical, "allowed_cpus": allowed,
+            "cgroup_cpu_quota": quota}
+
+
+def cgroup_cpu_quota():
+    """CPUs' worth of time this process's cgroup may use (cpu.max / cfs_quota), or None when unlimited.  A container on a
+    256-thread host is typically limited this way rather than by its affinity mask; starting one thread per physical
+    core of the HOST under such a quota makes the throttled threads spin on each other (measured on the 1-GPU box: 128
+    threads -> 13 s per step, an order of magnitude slower than 16)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2
+            q, p = f.read().split()
+            return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:          # cgroup v1
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
+def pick_threads(info: dict) -> dict:
+    """Thread count for the timing: the candidates (cgroup quota, affinity, physical cores and powers of two below them)
+    are tried on the path's dominant operation -- the (32 768 x 256) x (256 x 256) fp32 GEMM of one MLP layer on one
+    point chunk -- and the fastest wins, so neither an invisible CPU limit nor SMT siblings can make the baseline a
+    strawman.  Returns {threads, gemm_gflops: {n: rate}}."""
+    cap = min(info["physical_cores"], info["allowed_cpus"])
+    cands = {cap}
+    if info.get("cgroup_cpu_quota"):
+        cands.add(max(1, int(info["cgroup_cpu_quota"])))
+    n = 4
+    while n < cap:
+        cands.add(n)
+        n *= 2
+    a, w = torch.randn(32768, 256), torch.randn(256, 256)
+    rates = {}
+    for n in sorted(cands):
+        torch.set_num_threads(n)
+        for _ in range(2):
+            a @ w
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 0.25:
+            a @ w
+            reps += 1
+        rates[n] = reps * 2 * 32768 * 256 * 256 / (time.perf_counter() - t0) / 1e9
+    best = max(rates, key=rates.get)
+    return {"threads": best, "gemm_gflops": {str(k): round(v, 1) for k, v in rates.items()}}
 
 
 def timed_sample(mode: str, params_np, make_rays, make_target, budget_s: float = 12.0, n_rays: int = 1024,
@@ -186,6 +235,7 @@ def timed_sample(mode: str, params_np, make_rays, make_target, budget_s: float =
     batches of n_rays rays until ~budget_s seconds of work are done, after one untimed warm-up step.
     params_np: [coarse, fine] dicts of numpy arrays; make_rays(i) / make_target(i) -> numpy arrays."""
     info = host_info()
+    info.update(pick_threads(info))
     torch.set_num_threads(info["threads"])
     params = [{k: torch.from_numpy(v.copy()).requires_grad_(mode == "train") for k, v in p.items()} for p in params_np]
     opt = torch.optim.Adam([t for p in params for t in p.values()], lr=5e-4, eps=1e-8) if mode == "train" else None

@@ -11,6 +11,8 @@ Tolerances (also in DESIGN.md):
     rays whose searchsorted index flipped by a 1-ulp cdf difference are listed and
     held to 100x that.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -802,16 +804,12 @@ def test_eg3d_ray_limits_box_and_auto(golden, dev, osg):
 
 
 # --------------------------------------------------------------------------- PSNR parity (metric: "+ PSNR")
-@pytest.mark.parametrize("impl", ["torch", "fused", "fused+bf16x3"])
-def test_psnr_parity(golden, dev, impl):
-    """impl: torch.optim.Adam + elementwise loss, or training.FusedAdam + FusedMSELoss (one launch each), or the latter
-    with the opt-in split-bf16 math for the forward passes and the dX chain.
-    Teacher-scene protocol: the same 240 Adam steps the reference ran on CPU
-    (tools/make_psnr_golden.py: same teacher images, same batches, same injected random draws, same
-    initial weights, Adam lr 5e-4) on the HIP path; validation PSNR must agree within 0.1 dB (north_star)."""
+def _psnr_protocol(g, dev, impl):
+    """Teacher-scene protocol: the same Adam steps the reference ran on CPU
+    (tools/make_psnr_golden.py: same teacher images, same batches, same injected random draws, same initial weights,
+    same learning-rate schedule) on the HIP path -> validation-PSNR trajectory."""
     import nerf_siren_amd
     from nerf_siren_amd import Embedding, NeRF, render_rays
-    g = golden("g15_psnr")
     nerf_siren_amd.set_math("bf16x3" if impl.endswith("bf16x3") else "fp32")
     S, F, B = int(g["cfg_S"]), int(g["cfg_F"]), int(g["cfg_batch"])
     steps, every = int(g["cfg_steps"]), int(g["cfg_eval_every"])
@@ -821,8 +819,9 @@ def test_psnr_parity(golden, dev, impl):
         m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
         ms.append(m.to(dev))
     emb = [Embedding(3, 10), Embedding(3, 4)]
-    rays, tgt = T(g["rays"], dev), T(g["target"], dev)
-    val_rays, val_tgt = T(g["val_rays"], dev), T(g["val_target"], dev)
+    rays_np, val_np = synth.psnr_rays(g)
+    rays, tgt = T(rays_np, dev), T(g["target"], dev)
+    val_rays, val_tgt = T(val_np, dev), T(g["val_target"], dev)
     if impl.startswith("fused"):
         from nerf_siren_amd.training import FusedAdam, FusedMSELoss
         opt = FusedAdam(ms, lr=float(g["cfg_lr"]), eps=1e-8)
@@ -830,12 +829,20 @@ def test_psnr_parity(golden, dev, impl):
     else:
         opt = torch.optim.Adam([p for m in ms for p in m.parameters()], lr=float(g["cfg_lr"]), eps=1e-8)
         loss_fn = None
+    sched = None
+    if "cfg_lr_milestones" in g:                            # MultiStepLR, utils/__init__.py:33-50
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(v) for v in g["cfg_lr_milestones"]],
+                                                     gamma=float(g["cfg_lr_gamma"]))
     psnr = []
     for step in range(steps + 1):
         if step % every == 0:
+            se, n = 0.0, 0
             with torch.no_grad():
-                r = render_rays(ms, emb, val_rays, S, False, 0, 0, F, 1 << 15, True, False)
-            psnr.append(float(-10 * torch.log10(((r["rgb_fine"] - val_tgt) ** 2).mean())))
+                for i in range(0, val_rays.shape[0], 1 << 15):      # system.py:205: 32 768-ray chunks
+                    r = render_rays(ms, emb, val_rays[i:i + (1 << 15)], S, False, 0, 0, F, 1 << 15, True, False)
+                    se += float(((r["rgb_fine"] - val_tgt[i:i + (1 << 15)]).double() ** 2).sum())
+                    n += r["rgb_fine"].numel()
+            psnr.append(float(-10 * np.log10(se / n)))
         if step == steps:
             break
         idx = torch.from_numpy(synth.psnr_batch_indices(step, rays.shape[0], B)).to(dev)
@@ -849,11 +856,38 @@ def test_psnr_parity(golden, dev, impl):
         opt.zero_grad()
         loss.backward()
         opt.step()
+        if sched is not None:
+            sched.step()
     nerf_siren_amd.set_math("fp32")
+    return psnr
+
+
+@pytest.mark.parametrize("impl", ["torch", "fused", "fused+bf16x3"])
+def test_psnr_parity(golden, dev, impl):
+    """impl: torch.optim.Adam + elementwise loss, or training.FusedAdam + FusedMSELoss (one launch each), or the latter
+    with the opt-in split-bf16 math.  240 steps at 32x32 (g15); validation PSNR within 0.1 dB (north_star) at every
+    evaluation."""
+    g = golden("g15_psnr")
+    psnr = _psnr_protocol(g, dev, impl)
     ref = g["psnr"]
     print(impl, "psnr hip", np.round(psnr, 3), "reference", np.round(ref, 3))
     assert len(psnr) == len(ref)
     assert abs(psnr[0] - ref[0]) < 0.01                     # untrained: identical models
+    assert np.abs(np.array(psnr) - ref).max() < 0.1, (psnr, ref)
+
+
+def test_psnr_parity_long(golden, dev):
+    """The protocol at a horizon where the 0.1 dB bar bites (g19, tools/make_psnr_golden.py --long): 1 500 Adam steps of
+    1024 rays (configs[1]'s batch), learning rate halved at steps 600 and 1 200 (MultiStepLR), validation on a FULL
+    400x400 view (160 000 rays in 32 768-ray chunks) every 300 steps.  Every evaluation within 0.1 dB of the
+    reference's CPU run."""
+    g = golden("g19_psnr_long")
+    assert int(g["cfg_steps"]) >= 1500 and int(g["cfg_batch"]) == 1024 and int(g["cfg_val_res"]) == 400
+    psnr = _psnr_protocol(g, dev, "fused")
+    ref = g["psnr"]
+    print("long psnr hip", np.round(psnr, 3), "reference", np.round(ref, 3), "diff", np.round(np.array(psnr) - ref, 3))
+    assert len(psnr) == len(ref) == 6
+    assert abs(psnr[0] - ref[0]) < 0.01
     assert np.abs(np.array(psnr) - ref).max() < 0.1, (psnr, ref)
 
 
@@ -1276,3 +1310,336 @@ def test_fused_adam_checkpoint_resume(dev, models, tmp_path):
     for a, c in zip(ms_a, ms_c):
         for (k, p), q in zip(a.named_parameters(), c.parameters()):
             assert torch.equal(p, q), k
+
+
+# --------------------------------------------------------------------------- e: the HIP path under more than one rank
+def _ddp_models(dev):
+    from nerf_siren_amd import NeRF
+    ms = []
+    for seed in (1, 2):
+        m = NeRF()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, sigma_bias=0.5 * seed - 1.0).items()})
+        ms.append(m.to(dev))
+    return ms
+
+
+def _ddp_batch(n):
+    rays = synth.blender_rays(n, 71)
+    rng = dict(perturb_rand=synth.hash_uniform((n, 64), 72), noise_coarse=synth.hash_normal((n, 64), 73),
+               u=synth.hash_uniform((n, 64), 74), noise_fine=synth.hash_normal((n, 128), 75))
+    return rays, rng, synth.hash_uniform((n, 3), 76)
+
+
+def _ddp_step(models, dev, rays, rng, tgt, lo, hi):
+    from nerf_siren_amd import Embedding, render_rays
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    res = render_rays(models, emb, T(rays[lo:hi], dev), 64, False, 1.0, 1.0, 64, 1024 * 32, True, False,
+                      rng={k: T(v[lo:hi], dev) for k, v in rng.items()})
+    t = T(tgt[lo:hi], dev)
+    return ((res["rgb_coarse"] - t) ** 2).mean() + ((res["rgb_fine"] - t) ** 2).mean()     # losses.py:15-20
+
+
+def _ddp_worker(rank, world, port, n, overlap, q):
+    import torch.distributed as dist
+    from nerf_siren_amd.parallel import FlatGradAllReduce, shard_rays
+    from nerf_siren_amd.training import FusedAdam
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")                              # the ranks share the box's one GPU (rehearsal of dp-N)
+    models = _ddp_models(dev)
+    opt = FusedAdam(models, lr=5e-4, eps=1e-8)
+    reducer = FlatGradAllReduce(models, world, overlap=overlap)
+    assert reducer.joint is not None and reducer.overlap == overlap
+    rays, rng, tgt = _ddp_batch(n)
+    lo, hi = shard_rays(n, rank, world)
+    opt.zero_grad(set_to_none=True)
+    _ddp_step(models, dev, rays, rng, tgt, lo, hi).backward()
+    bufs = reducer.all_reduce(average=False)                  # SUM over ranks; the 1/world rides in the Adam kernel
+    assert len(bufs) == 1 and bufs[0].data_ptr() == reducer.joint.data_ptr()
+    grads = (reducer.joint / world).cpu()
+    opt.step(grad_scale=1.0 / world)
+    params = torch.cat([p.detach().reshape(-1) for m in models for p in m.param_list()]).cpu()
+    torch.cuda.synchronize()
+    q.put((rank, grads.numpy(), params.numpy()))          # by value: torch tensors would travel as shared-memory handles
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_hip_gradients_match_single_rank(dev, overlap):
+    """Two ranks (gloo, sharing cuda:0) run the REAL HIP path on their shards of one batch: HIP backward into the joint
+    gradient buffer, FlatGradAllReduce (one joint collective, or the fine model's slice reduced while the coarse
+    backward runs), FusedAdam(grad_scale = 1/world).  The reduced gradient and the updated parameters must equal a
+    single-rank step on the concatenated batch (train.py:41-66 DDP semantics: mean over ranks of per-rank means)."""
+    import torch.multiprocessing as mp
+    import socket
+    from nerf_siren_amd.training import FusedAdam
+    world, n = 2, 128
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, n, overlap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, g, prm = q.get(timeout=240)
+        got[r] = (torch.from_numpy(g), torch.from_numpy(prm))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single rank, whole batch
+    models = _ddp_models(dev)
+    opt = FusedAdam(models, lr=5e-4, eps=1e-8)
+    rays, rng, tgt = _ddp_batch(n)
+    opt.zero_grad(set_to_none=True)
+    _ddp_step(models, dev, rays, rng, tgt, 0, n).backward()
+    ref_g = torch.cat([p.grad.reshape(-1) for m in models for p in m.param_list()]).cpu()
+    opt.step()
+    ref_p = torch.cat([p.detach().reshape(-1) for m in models for p in m.param_list()]).cpu()
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])      # replicas stay identical
+    rel = float((got[0][0] - ref_g).double().norm() / ref_g.double().norm())
+    assert rel < 1e-5, rel                                   # split-K over ranks vs over tiles: summation order only
+    # Adam's first step moves every weight by ~lr * g / (|g| + eps): equal up to entries with |g| ~ eps
+    assert float((got[0][1] - ref_p).abs().max()) <= 2 * 5e-4 + 1e-9
+    assert float(((got[0][1] - ref_p).abs() > 1e-6).float().mean()) < 1e-3
+
+
+# --------------------------------------------------------------------------- f1 / f3 against the reference's own outputs
+def test_ray_generation_vs_reference_fixture(golden, ops, dev):
+    """The HIP ray-generation kernels against datasets/ray_utils.py:5-93 itself (fixture g20, generated by running the
+    reference file): get_ray_directions, get_rays, get_ndc_rays and the fused generate_rays rows."""
+    from nerf_siren_amd import ray_utils as RU
+    g = golden("g20_ray_utils")
+    for t in ("b", "l"):
+        H, W, focal = int(g[t + "_H"]), int(g[t + "_W"]), float(g[t + "_focal"])
+        dirs = RU.get_ray_directions(H, W, focal, dev)
+        assert np.array_equal(N(dirs), g[t + "_directions"])
+        o, d = RU.get_rays(dirs, T(g[t + "_c2w"], dev))
+        assert np.array_equal(N(o), g[t + "_rays_o"])
+        np.testing.assert_allclose(N(d), g[t + "_rays_d"], rtol=0, atol=1.2e-7)     # matmul + norm order: 1 ulp
+    H, W, focal = int(g["l_H"]), int(g["l_W"]), float(g["l_focal"])
+    no, nd = RU.get_ndc_rays(H, W, focal, 1.0, T(g["l_rays_o"], dev), T(g["l_rays_d"], dev))
+    np.testing.assert_allclose(N(no), g["l_ndc_o"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(N(nd), g["l_ndc_d"], rtol=2e-6, atol=2e-7)
+    rays = N(RU.generate_rays(T(g["b_c2w"][None], dev), int(g["b_H"]), int(g["b_W"]), float(g["b_focal"])))
+    assert np.array_equal(rays[:, :3], g["b_rays_o"]) and np.all(rays[:, 6] == 2.0) and np.all(rays[:, 7] == 6.0)
+    np.testing.assert_allclose(rays[:, 3:6], g["b_rays_d"], rtol=0, atol=1.2e-7)
+    rays = N(RU.generate_rays(T(g["l_c2w"][None], dev), H, W, focal, ndc=True, near=1.0))
+    np.testing.assert_allclose(rays[:, :3], g["l_ndc_o"], rtol=2e-6, atol=3e-7)
+    np.testing.assert_allclose(rays[:, 3:6], g["l_ndc_d"], rtol=2e-6, atol=3e-7)
+    assert np.all(rays[:, 6] == 0.0) and np.all(rays[:, 7] == 1.0)                  # llff.py:236-250: NDC near 0 / far 1
+
+
+def test_grid_queries_vs_reference_fixture(golden, dev):
+    """Device grid builders / packers against the reference's own expressions (fixture g21): mesh grid order and sigma
+    clamp (extract_color_mesh.py:117-140), create_samples (extract_color_mesh_eg3d.py:72-94), .vol records
+    (extract_mesh.ipynb cell 7)."""
+    from nerf_siren_amd import field_query as FQ
+    g = golden("g21_grids")
+    n = int(g["mesh_N"])
+    pts = FQ.grid_points(n, *[tuple(r) for r in g["mesh_ranges"]], dev)
+    assert np.array_equal(N(pts), g["mesh_xyz"])
+    for k in (6, 32):
+        smp, origin, vs = FQ.create_samples(k, (0, 0, 0), float(g[f"cs{k}_cube"]), device=dev)
+        assert np.array_equal(origin, g[f"cs{k}_origin"]) and vs == float(g[f"cs{k}_voxel_size"])
+        np.testing.assert_allclose(N(smp), g[f"cs{k}_samples"], rtol=0, atol=2.4e-7)
+    vol = FQ.pack_vol(T(g["vol_rgbsigma"], dev), int(g["vol_N"]), float(g["vol_extent"]))
+    ref = g["vol_records"]
+    assert vol.dtype == np.uint32 and vol.shape == ref.shape and np.array_equal(vol[0::2], ref[0::2])
+    # exp() may differ by 1 ulp between libm and the device: the alpha byte may differ by one count on a few records
+    assert (np.abs(vol[1::2].astype(np.int64) - ref[1::2].astype(np.int64)) <= 1).all() and (vol == ref).mean() > 0.98
+
+
+# --------------------------------------------------------------------------- full-size C4 / C5 (property tests)
+def test_c4_llff_ndc_full_size(dev, models):
+    """BASELINE configs[3]: LLFF fern 504x378, NDC rays (near 0 / far 1, non-unit directions, white_back False),
+    batch 4096, 64+64: determinism, ray independence, finite outputs, sorted merged depths inside [near, far], and an
+    oracle comparison on a 256-ray subset (free-running, same conditioned rule as the golden cases)."""
+    from nerf_siren_amd import Embedding, render_rays
+    params, ms = models
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    n = 4096
+    rays_np = synth.ndc_rays(n, 61)
+    rays = T(rays_np, dev)
+    rng_np = dict(perturb_rand=synth.hash_uniform((n, 64), 62), noise_coarse=synth.hash_normal((n, 64), 63),
+                  u=synth.hash_uniform((n, 64), 64), noise_fine=synth.hash_normal((n, 128), 65))
+    rng = {k: T(v, dev) for k, v in rng_np.items()}
+    aux = {}
+    with torch.no_grad():
+        r1 = render_rays(ms, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, False, False, rng=rng, aux=aux)
+        r2 = render_rays(ms, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, False, False, rng=rng)
+        sub = slice(1000, 1256)
+        r3 = render_rays(ms, emb, rays[sub], 64, False, 1.0, 1.0, 64, 1024 * 32, False, False,
+                         rng={k: v[sub] for k, v in rng.items()})
+    zf = aux["z_fine"]
+    assert zf.shape == (n, 128) and bool((zf[:, 1:] >= zf[:, :-1]).all()) and float(zf.min()) >= 0.0 and float(zf.max()) <= 1.0
+    for k in r1:
+        assert torch.isfinite(r1[k]).all(), k
+        assert torch.equal(r1[k], r2[k]), k                   # deterministic
+        assert torch.equal(r1[k][sub], r3[k]), k              # a ray's result does not depend on its batch
+    assert float(r1["opacity_fine"].max()) <= 1 + 1e-5 and float(r1["opacity_coarse"].min()) >= 0
+    ref = O.render_rays(params, rays_np[sub], 64, False, 1.0, 1.0, 64, False, False, rng={k: v[sub] for k, v in rng_np.items()})
+    moved = np.abs(N(zf)[sub] - ref["_aux"]["z_fine"]).max(-1) > 1e-5
+    assert moved.mean() <= 0.25, moved.mean()
+    for k in r1:
+        err = np.abs(N(r1[k])[sub] - ref[k]).reshape(256, -1).max(-1)
+        loose = moved & ("fine" in k)
+        assert np.all(err[~loose] <= 1e-4) and np.all(err <= 1e-2), (k, err.max())
+
+
+@pytest.fixture(scope="module")
+def eg3d_full(dev):
+    from nerf_siren_amd import OSGDecoder
+    dp = synth.osg_params(4)
+    dec = OSGDecoder(32, {"decoder_lr_mul": 1.0, "decoder_output_dim": 3})
+    dec.load_state_dict({k: torch.from_numpy(v) for k, v in dp.items()})
+    planes_np = synth.triplanes(9, res=256)
+    return dp, dec.to(dev), planes_np, T(planes_np, dev)
+
+
+def test_c5_eg3d_full_size_forward_backward(dev, eg3d_full):
+    """BASELINE configs[4] at its real size: planes (1,3,32,256,256), M = 4096 rays x (64+64), forward and backward
+    (gradients to planes and decoder): determinism, ray independence of everything but the GLOBAL depth clamp
+    (ray_marcher.py:49-50), finite values, depth inside the global [min, max] of its call, an oracle comparison on a
+    256-ray subset, and bit-reproducible decoder gradients (deterministic slab reduction)."""
+    from nerf_siren_amd import ImportanceRenderer
+    dp, dec, planes_np, planes = eg3d_full
+    M = 4096
+    o_np, d_np = synth.eg3d_rays(M, 5)
+    rs, u = synth.hash_uniform((1, M, 64, 1), 81), synth.hash_uniform((M, 64), 82)
+    opts = dict(synth.EG3D_OPTIONS, rng_stratified=T(rs, dev), rng_importance=T(u, dev))
+    ren = ImportanceRenderer()
+    o, d = T(o_np[None], dev), T(d_np[None], dev)
+    with torch.no_grad():
+        a = ren(planes, dec, o, d, opts)
+        b = ren(planes, dec, o, d, opts)
+    for x, y in zip(a, b):
+        assert torch.isfinite(x).all() and torch.equal(x, y)
+    rgb_c, depth_c, w_c, rgb_f, depth_f, w_f = a
+    assert rgb_f.shape == (1, M, 3) and depth_f.shape == (1, M, 1)
+    assert float(w_f.max()) <= 1 + 1e-5 and float(w_c.min()) >= 0
+    assert 0.1 <= float(depth_f.min()) and float(depth_f.max()) <= 10.0           # clamp to the call's sampled depth range
+    # a 256-ray sub-call: colours and weight sums are per-ray quantities (depth is clamped with the sub-call's own range)
+    sub = slice(512, 768)
+    so = dict(opts, rng_stratified=opts["rng_stratified"][:, sub], rng_importance=opts["rng_importance"][sub])
+    with torch.no_grad():
+        c = ren(planes, dec, o[:, sub], d[:, sub], so)
+    for i in (0, 2, 3, 5):
+        assert torch.equal(a[i][:, sub], c[i]), i
+    ref = EO.importance_renderer(planes_np, dp, o_np[None, sub], d_np[None, sub], synth.EG3D_OPTIONS, rs[:, sub], u[sub])
+    for i, name in ((0, "rgb_c"), (2, "op_c"), (3, "rgb_f"), (5, "op_f")):
+        err = np.abs(N(c[i]) - ref[i]).reshape(256, -1).max(-1)
+        assert (err <= 1e-4).mean() >= 0.9 and err.max() <= 1e-2, (name, err.max())
+        if name.endswith("_c"):
+            assert err.max() <= 1e-4, (name, err.max())
+    # backward at full size
+    pl = planes.clone().requires_grad_(True)
+    grads = []
+    for _ in range(2):
+        pl.grad = None
+        for p in dec.parameters():
+            p.grad = None
+        out = ren(pl, dec, o, d, opts)
+        (out[3].square().mean() + 0.1 * out[4].mean() + out[0].square().mean() - 0.2 * out[5].mean()).backward()
+        grads.append([p.grad.clone() for p in dec.parameters()] + [pl.grad.clone()])
+    for x, y in zip(grads[0][:-1], grads[1][:-1]):
+        assert torch.isfinite(x).all() and torch.equal(x, y)                       # decoder gradients: bit-reproducible
+    gp0, gp1 = grads[0][-1], grads[1][-1]
+    assert gp0.shape == planes.shape and torch.isfinite(gp0).all() and float(gp0.abs().max()) > 0
+    # plane gradients are float atomics: equal up to summation order
+    assert float((gp0 - gp1).abs().max()) <= 1e-5 * float(gp0.abs().max()) + 1e-9
+    for p in dec.parameters():
+        p.grad = None
+
+
+def test_c5_eg3d_dense_query_full_size(dev, eg3d_full):
+    """The 128^3 = 2 097 152-point "neural volume" of configs[4] (extract_color_mesh_eg3d.py:177-195: create_samples ->
+    run_model in slabs -> flip): slab size does not change a single bit, values are finite, and a 4096-point subset
+    matches the oracle's sample_from_planes + OSGDecoder."""
+    from nerf_siren_amd import ImportanceRenderer, field_query as FQ
+    dp, dec, planes_np, planes = eg3d_full
+    ren = ImportanceRenderer()
+    opts = dict(synth.EG3D_OPTIONS)
+    g1 = FQ.eg3d_sigma_grid(ren, planes, dec, opts, N=128, cube_length=3.0, max_batch=1000000)
+    g2 = FQ.eg3d_sigma_grid(ren, planes, dec, opts, N=128, cube_length=3.0, max_batch=300007)
+    assert g1.shape == (128, 128, 128) and torch.isfinite(g1).all() and torch.equal(g1, g2)
+    samples, _, _ = FQ.create_samples(128, (0, 0, 0), 3.0, device=dev)
+    idx = (synth.hash_uniform((4096,), 83) * 128 ** 3).astype(np.int64).clip(0, 128 ** 3 - 1)
+    pts = N(samples)[0, idx]
+    with torch.no_grad():
+        out = ren.run_model(planes, dec, T(pts[None], dev), None, opts)
+    ref_rgb, ref_sigma = EO.run_model(planes_np, dp, pts[None], 15.0)
+    np.testing.assert_allclose(N(out["sigma"]).reshape(-1), ref_sigma.reshape(-1), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(N(out["rgb"]).reshape(-1, 3), ref_rgb.reshape(-1, 3), rtol=0, atol=1e-5)
+    flat = N(torch.flip(g1, (0,)).reshape(-1))
+    np.testing.assert_allclose(flat[idx], ref_sigma.reshape(-1), rtol=2e-5, atol=2e-5)
+
+
+def test_eg3d_fresh_planes_at_a_recycled_address(dev, eg3d_full):
+    """Round-1 advisor finding: the channels-last plane image was cached by (address, version), so a fresh activation
+    that the caching allocator placed at a freed tensor's address rendered with the PREVIOUS planes.  Two different plane
+    tensors at the same address through one renderer must give their own results."""
+    from nerf_siren_amd import ImportanceRenderer
+    _, dec, _, _ = eg3d_full
+    ren = ImportanceRenderer()
+    opts = dict(synth.EG3D_OPTIONS)
+    pts = T(((synth.hash_uniform((1, 500, 3), 84) * 2 - 1) * 6.0).astype(np.float32), dev)
+    outs, ptrs = [], []
+    for seed in (21, 22):
+        p = T(synth.triplanes(seed, res=32), dev)                 # a fresh tensor each round, freed afterwards
+        ptrs.append(p.data_ptr())
+        with torch.no_grad():
+            outs.append(ren.run_model(p, dec, pts, None, opts)["sigma"].clone())
+        expect = ImportanceRenderer().run_model(p, dec, pts, None, opts)["sigma"]
+        assert torch.equal(outs[-1], expect)
+        del p, expect
+    assert ptrs[0] == ptrs[1], "the allocator did not recycle the address (test needs it to)"
+    assert not torch.equal(outs[0], outs[1])
+
+
+# --------------------------------------------------------------------------- NeRF.forward(x) with autograd (module API)
+def test_nerf_module_forward_autograd(dev, models):
+    """models/nerf.py:83-124 is a differentiable nn.Module: NeRF()(x) on pre-embedded rows under grad must give the
+    gradients of all 24 parameters (oracle's manual backward, itself pinned by the reference's autograd in G7), for the
+    full and the sigma_only call; gradients w.r.t. x are refused loudly."""
+    params, ms = models
+    p, m = params[1], ms[1]
+    B = 77                                                     # ragged: two full 32-point tiles + 13
+    pts = ((synth.hash_uniform((B, 3), 901) * 2 - 1) * 3).astype(np.float32)
+    dirs = synth.blender_rays(B, 902)[:, 3:6]
+    x = np.concatenate([O.embed(pts, 10), O.embed(dirs, 4)], -1).astype(np.float32)
+    G = synth.hash_normal((B, 4), 903)
+    m.zero_grad()
+    out = m(T(x, dev))
+    assert out.requires_grad and out.shape == (B, 4)
+    ref, cache = O.nerf_forward(p, x, keep=True)
+    np.testing.assert_allclose(N(out), ref, rtol=3e-5, atol=3e-5)
+    (out * T(G, dev)).sum().backward()
+    og = O.nerf_backward(p, cache, G)
+    for k, q in m.named_parameters():
+        r = _rel(N(q.grad), og[k])
+        assert r < 5e-3, (k, r)
+    # sigma_only=True (nerf.py:112-114): only the xyz trunk and the sigma head receive gradient
+    m.zero_grad()
+    sig = m(T(x[:, :63], dev), sigma_only=True)
+    assert sig.shape == (B, 1) and sig.requires_grad
+    sref, scache = O.nerf_forward(p, x[:, :63], sigma_only=True, keep=True)
+    np.testing.assert_allclose(N(sig), sref, rtol=3e-5, atol=3e-5)
+    (sig * T(G[:, 3:4], dev)).sum().backward()
+    sg = O.nerf_backward(p, scache, G[:, 3:4], sigma_only=True)
+    for k, q in m.named_parameters():
+        if k in sg:
+            assert _rel(N(q.grad), sg[k]) < 5e-3, k
+        else:
+            assert float(q.grad.abs().max()) == 0.0, k        # colour branch: exact zeros
+    m.zero_grad()
+    with pytest.raises(NotImplementedError):
+        m(T(x, dev).requires_grad_(True))
+    with torch.no_grad():
+        assert not m(T(x, dev)).requires_grad

@@ -399,7 +399,42 @@ def test_torch_cpu_ref_vs_reference(golden, case):
 def test_torch_cpu_ref_host_info_and_sample():
     from oracle import torch_cpu_ref as TR
     info = TR.host_info()
-    assert info["physical_cores"] >= 1 and 1 <= info["threads"] <= info["nproc"] and info["cpu_model"]
+    assert info["physical_cores"] >= 1 and info["cpu_model"] and info["allowed_cpus"] >= 1
     ps = [synth.nerf_params(1, False), synth.nerf_params(2, False)]
     out = TR.timed_sample("infer", ps, lambda i: synth.blender_rays(64, seed=i), None, budget_s=0.2, n_rays=64, max_steps=2)
     assert out["steps"] >= 1 and out["ray_samples_per_s"] > 0 and "parallel_info" in out
+    assert 1 <= out["threads"] <= out["nproc"] and str(out["threads"]) in out["gemm_gflops"]
+
+
+# --------------------------------------------------------------------------- f1 / f3 pinned by the reference's own code
+def test_ray_utils_oracle_vs_reference(golden):
+    """datasets/ray_utils.py:5-93 run from the reference file (tools/make_golden.py:g_ray_utils; kornia 0.2.0's
+    create_meshgrid supplied from its published definition) vs the restatement."""
+    g = golden("g20_ray_utils")
+    for t in ("b", "l"):
+        H, W, focal = int(g[t + "_H"]), int(g[t + "_W"]), float(g[t + "_focal"])
+        d = O.ray_directions(H, W, focal)
+        assert np.array_equal(d, g[t + "_directions"])
+        o, rd = O.get_rays(d, g[t + "_c2w"])
+        assert np.array_equal(o, g[t + "_rays_o"])
+        np.testing.assert_allclose(rd, g[t + "_rays_d"], rtol=0, atol=1.2e-7)       # matmul + norm order: 1 ulp
+    no, nd = O.ndc_rays(int(g["l_H"]), int(g["l_W"]), float(g["l_focal"]), 1.0, g["l_rays_o"], g["l_rays_d"])
+    np.testing.assert_allclose(no, g["l_ndc_o"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(nd, g["l_ndc_d"], rtol=2e-6, atol=2e-7)
+
+
+def test_grid_queries_oracle_vs_reference(golden):
+    """extract_color_mesh.py:117-140 (grid order, sigma clamp), extract_color_mesh_eg3d.py:72-94 (create_samples) and
+    extract_mesh.ipynb cell 7 (.vol records), all executed from the reference's own text (tools/make_golden.py:g_grid)."""
+    g = golden("g21_grids")
+    N = int(g["mesh_N"])
+    pts = O.grid_points(N, *[tuple(r) for r in g["mesh_ranges"]])
+    assert np.array_equal(pts, g["mesh_xyz"])
+    assert np.array_equal(np.maximum(g["mesh_sigma_in"], 0).reshape(N, N, N), g["mesh_sigma_grid"])
+    for n in (6, 32):
+        smp, origin, vs = O.create_samples(n, [0, 0, 0], float(g[f"cs{n}_cube"]))
+        assert np.array_equal(origin, g[f"cs{n}_origin"]) and vs == float(g[f"cs{n}_voxel_size"])
+        assert smp.shape == g[f"cs{n}_samples"].shape
+        np.testing.assert_allclose(smp, g[f"cs{n}_samples"], rtol=0, atol=2.4e-7)
+    vol = O.pack_vol(g["vol_rgbsigma"], int(g["vol_N"]), float(g["vol_extent"]))
+    assert vol.dtype == np.uint32 and np.array_equal(vol, g["vol_records"])

@@ -510,7 +510,112 @@ def g_pfm():
     save("g18_pfm", **out)
 
 
+# --------------------------------------------------------------------------- G20: ray generation (section 8 f1)
+def g_ray_utils():
+    """datasets/ray_utils.py:5-93 executed from the reference file itself (loaded by path: the `datasets` package
+    __init__ needs torchvision/cv2).  Its one third-party import, `from kornia import create_meshgrid`
+    (kornia==0.2.0, requirements.txt:6, absent here), is satisfied with that function's published definition:
+    pixel coordinates xs = linspace(0, W-1, W), ys = linspace(0, H-1, H), grid (1,H,W,2) with [...,0] = x, [...,1] = y."""
+    import importlib.util
+    import types
+
+    def create_meshgrid(height, width, normalized_coordinates=True):
+        if normalized_coordinates:
+            xs, ys = torch.linspace(-1, 1, width), torch.linspace(-1, 1, height)
+        else:
+            xs, ys = torch.linspace(0, width - 1, width), torch.linspace(0, height - 1, height)
+        base = torch.stack(torch.meshgrid([xs, ys], indexing="ij")).transpose(1, 2)      # 2 x H x W
+        return base.unsqueeze(0).permute(0, 2, 3, 1)                                      # 1 x H x W x 2
+
+    k = types.ModuleType("kornia")
+    k.create_meshgrid = create_meshgrid
+    sys.modules["kornia"] = k
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_ray_utils", "/root/reference/datasets/ray_utils.py")
+        RU = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(RU)
+    finally:
+        del sys.modules["kornia"]
+    out = {}
+    # blender-like (blender.py:60-69): odd sizes, unit-norm world directions
+    H, W, focal = 13, 17, 21.5
+    c2w = synth._look_at_c2w(0.4, 1.1, synth.LEGO_RADIUS).astype(np.float32)
+    dirs = RU.get_ray_directions(H, W, focal)
+    o, d = RU.get_rays(dirs, torch.from_numpy(c2w))
+    out.update(b_H=H, b_W=W, b_focal=focal, b_c2w=c2w, b_directions=dirs, b_rays_o=o, b_rays_d=d)
+    # LLFF-like (llff.py:234-250): forward-facing pose near identity, NDC with the near plane at 1.0
+    H, W = 12, 16
+    focal = 0.809 * W
+    c2w = np.eye(4, dtype=np.float32)[:3]
+    c2w[:, :3] += (synth.hash_normal((3, 3), 601) * 0.05).astype(np.float32)
+    c2w[:, 3] = (synth.hash_normal((3,), 602) * 0.3).astype(np.float32)
+    dirs = RU.get_ray_directions(H, W, focal)
+    o, d = RU.get_rays(dirs, torch.from_numpy(c2w))
+    no, nd = RU.get_ndc_rays(H, W, focal, 1.0, o, d)
+    out.update(l_H=H, l_W=W, l_focal=focal, l_c2w=c2w, l_directions=dirs, l_rays_o=o, l_rays_d=d, l_ndc_o=no, l_ndc_d=nd)
+    save("g20_ray_utils", **out)
+
+
+# --------------------------------------------------------------------------- G21: dense-grid queries (section 8 f3)
+def g_grid():
+    """Grid order + sigma clamp of extract_color_mesh.py:117-140, create_samples of extract_color_mesh_eg3d.py:72-94 and
+    the .vol packing of extract_mesh.ipynb cell 7.  Those files import mcubes / open3d / cv2 / datasets (absent) and the
+    first and third are inline script code, so the reference's OWN expressions / function / cell are pulled out of the
+    files with `ast` and executed here on small inputs."""
+    import ast
+    import json
+    out = {}
+    # (1) extract_color_mesh.py: x, y, z, xyz_ (without the trailing .cuda()), sigma = np.maximum(sigma, 0).reshape(N, N, N)
+    tree = ast.parse(open("/root/reference/extract_color_mesh.py").read())
+    N = 5
+    env = {"np": np, "torch": torch, "N": N, "xmin": -1.2, "xmax": 1.2, "ymin": -1.0, "ymax": 1.1, "zmin": -0.9, "zmax": 1.2}
+    done = set()
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name):
+            name, val = node.targets[0].id, node.value
+            src = ast.unparse(val)
+            if name in ("x", "y", "z") and src.startswith("np.linspace(") and name not in done:
+                env[name] = eval(src, env)
+                done.add(name)
+            elif name == "xyz_" and src.endswith(".cuda()") and "meshgrid" in src and name not in done:
+                env[name] = eval(ast.unparse(val.func.value), env)               # the expression in front of .cuda()
+                done.add(name)
+    assert done == {"x", "y", "z", "xyz_"}, done
+    sig_in = (synth.hash_normal((N ** 3,), 611) * 3).astype(np.float32)
+    clamp = [ast.unparse(n.value) for n in ast.walk(tree) if isinstance(n, ast.Assign) and isinstance(n.targets[0], ast.Name)
+             and n.targets[0].id == "sigma" and "np.maximum" in ast.unparse(n.value)]
+    assert len(clamp) == 1, clamp
+    out.update(mesh_N=N, mesh_ranges=np.array([[-1.2, 1.2], [-1.0, 1.1], [-0.9, 1.2]]), mesh_xyz=env["xyz_"],
+               mesh_sigma_in=sig_in, mesh_sigma_grid=eval(clamp[0], {"np": np, "N": N, "sigma": sig_in}))
+    # (2) extract_color_mesh_eg3d.py: def create_samples
+    src = open("/root/reference/extract_color_mesh_eg3d.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "create_samples"]
+    ns = {"np": np, "torch": torch}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "extract_color_mesh_eg3d.py", "exec"), ns)
+    for n, cube in ((6, 3.0), (32, 2.0)):
+        smp, origin, vs = ns["create_samples"](N=n, voxel_origin=[0, 0, 0], cube_length=cube)
+        out.update({f"cs{n}_samples": smp, f"cs{n}_origin": np.asarray(origin, np.float64), f"cs{n}_voxel_size": np.float64(vs),
+                    f"cs{n}_cube": np.float64(cube)})
+    # (3) extract_mesh.ipynb cell 7 (.vol records), without its `assert N==512` and the file write
+    nb = json.load(open("/root/reference/extract_mesh.ipynb"))
+    cell = [c for c in nb["cells"] if c["cell_type"] == "code" and ".vol" in "".join(c["source"])]
+    assert len(cell) == 1
+    body = [n for n in ast.parse("".join(cell[0]["source"])).body if not isinstance(n, (ast.Assert, ast.With))]
+    Nv = 6
+    rs = synth.hash_uniform((Nv ** 3, 4), 612)
+    rs[:, 3] = rs[:, 3] * 40 - 20                                         # both a == 0 and a > 0 occur
+    envv = {"np": np, "N": Nv, "xmin": -1.2, "xmax": 1.2, "rgbsigma": torch.from_numpy(rs.copy()),
+            "sigma": np.maximum(rs[:, 3], 0).reshape(Nv, Nv, Nv)}       # cell 4: the clamped grid
+    exec(compile(ast.Module(body=body, type_ignores=[]), "extract_mesh.ipynb#7", "exec"), envv)
+    out.update(vol_N=Nv, vol_extent=np.float64(2.4), vol_rgbsigma=rs, vol_records=envv["res"])
+    save("g21_grids", **out)
+
+
 def main():
+    if "--only-rays" in sys.argv:
+        return g_ray_utils()
+    if "--only-grid" in sys.argv:
+        return g_grid()
     if "--only-pfm" in sys.argv:
         return g_pfm()
     if "--only-loss" in sys.argv:
@@ -521,6 +626,8 @@ def main():
         return g_siren()
     if "--only-eg3d" in sys.argv:
         return g_eg3d()
+    g_ray_utils()
+    g_grid()
     g_eg3d()
     g_eg3d_grad()
     g_siren()

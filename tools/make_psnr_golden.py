@@ -25,20 +25,14 @@ from models.nerf import Embedding, NeRF           # noqa: E402
 from nerf_siren_amd import synth                  # noqa: E402
 
 CFG = dict(res=32, n_train_views=8, batch=512, steps=240, eval_every=60, lr=5e-4, S=64, F=64)
+# --long (g19): the protocol at a horizon where a 0.1 dB bar bites -- 1 500 steps of 1024 rays (configs[1]'s batch), the
+# learning rate halved at steps 600 and 1 200 (MultiStepLR, utils/__init__.py:33-50), validation on a FULL 400x400 view
+# (160 000 rays) every 300 steps.  Rays are regenerated from the view seeds (synth.psnr_rays); the fixture stores the
+# teacher's images only.
+CFG_LONG = dict(res=64, n_train_views=24, val_res=400, batch=1024, steps=1500, eval_every=300, lr=5e-4, S=64, F=64,
+                lr_milestones=[600, 1200], lr_gamma=0.5)
 
-
-def view_rays(res, view_seed):
-    """All res*res rays of one lego-like camera (same geometry as synth.blender_rays)."""
-    uv = synth.hash_uniform((1, 2), view_seed * 7919 + 11)
-    c2w = synth._look_at_c2w(float(uv[0, 0]) * np.deg2rad(60.0), float(uv[0, 1]) * 2 * np.pi, synth.LEGO_RADIUS)
-    focal = np.float32(0.5 * res / np.tan(0.5 * synth.LEGO_ANGLE_X))
-    j, i = np.meshgrid(np.arange(res, dtype=np.float32), np.arange(res, dtype=np.float32), indexing="ij")
-    dirs = np.stack([(i - res / 2) / focal, -(j - res / 2) / focal, -np.ones_like(i)], -1).reshape(-1, 3).astype(np.float32)
-    d = (dirs @ c2w[:, :3].T).astype(np.float32)
-    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
-    o = np.broadcast_to(c2w[:, 3], d.shape)
-    nf = np.tile(np.array([[2.0, 6.0]], np.float32), (d.shape[0], 1))
-    return np.concatenate([o, d, nf], -1).astype(np.float32)
+view_rays = synth.view_rays
 
 
 step_rng = synth.psnr_step_rng            # shared with tests/test_gpu_parity.py::test_psnr_parity
@@ -60,8 +54,9 @@ def patched(rng_list):
 
 
 def main():
-    torch.set_num_threads(8)
-    c = CFG
+    torch.set_num_threads(int(os.environ.get("PSNR_THREADS", "8")))
+    long = "--long" in sys.argv
+    c = CFG_LONG if long else CFG
     emb = [Embedding(3, 10), Embedding(3, 4)]
 
     def model(p):
@@ -71,20 +66,27 @@ def main():
 
     teacher = [model(synth.nerf_params(7, sigma_bias=-0.5)), model(synth.nerf_params(8, sigma_bias=0.5))]
     rays = np.concatenate([view_rays(c["res"], 300 + v) for v in range(c["n_train_views"])], 0)
-    val_rays = view_rays(c["res"], 399)
-    with torch.no_grad():
-        tgt = R.render_rays(teacher, emb, torch.from_numpy(rays), c["S"], False, 0, 0, c["F"], 1 << 15, True, True)["rgb_fine"].numpy()
-        val_tgt = R.render_rays(teacher, emb, torch.from_numpy(val_rays), c["S"], False, 0, 0, c["F"], 1 << 15, True, True)["rgb_fine"].numpy()
+    val_rays = view_rays(c.get("val_res", c["res"]), 399)
+
+    def render(models, rr, test_time):
+        out = []
+        with torch.no_grad():
+            for i in range(0, rr.shape[0], 1 << 15):                 # system.py:205 / eval.py:80: 32 768-ray chunks
+                out.append(R.render_rays(models, emb, torch.from_numpy(rr[i:i + (1 << 15)]), c["S"], False, 0, 0, c["F"],
+                                         1 << 15, True, test_time)["rgb_fine"].numpy())
+        return np.concatenate(out, 0)
+
+    tgt, val_tgt = render(teacher, rays, True), render(teacher, val_rays, True)
     print("teacher rendered", tgt.shape, "mean", tgt.mean(0), "std", tgt.std(0))
 
     student = [model(synth.nerf_params(11, structured=False)), model(synth.nerf_params(12, structured=False))]
     opt = torch.optim.Adam([p for m in student for p in m.parameters()], lr=c["lr"], eps=1e-8)
+    sched = (torch.optim.lr_scheduler.MultiStepLR(opt, milestones=c["lr_milestones"], gamma=c["lr_gamma"])
+             if "lr_milestones" in c else None)
     psnr, losses = [], []
 
     def evaluate():
-        with torch.no_grad():
-            r = R.render_rays(student, emb, torch.from_numpy(val_rays), c["S"], False, 0, 0, c["F"], 1 << 15, True, False)
-        mse = float(((r["rgb_fine"].numpy() - val_tgt) ** 2).mean())
+        mse = float(((render(student, val_rays, False).astype(np.float64) - val_tgt) ** 2).mean())
         return -10 * np.log10(mse)
 
     t0 = time.time()
@@ -103,10 +105,17 @@ def main():
         opt.zero_grad()
         loss.backward()
         opt.step()
+        if sched is not None:
+            sched.step()
         losses.append(float(loss))
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g15_psnr.npz"), rays=rays, target=tgt, val_rays=val_rays,
-                        val_target=val_tgt, psnr=np.array(psnr, np.float32), losses=np.array(losses, np.float32),
-                        **{"cfg_" + k: v for k, v in c.items()})
+    if long:
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g19_psnr_long.npz"), target=tgt, val_target=val_tgt,
+                            psnr=np.array(psnr, np.float32), losses=np.array(losses, np.float32),
+                            **{"cfg_" + k: v for k, v in c.items()})
+    else:
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g15_psnr.npz"), rays=rays, target=tgt, val_rays=val_rays,
+                            val_target=val_tgt, psnr=np.array(psnr, np.float32), losses=np.array(losses, np.float32),
+                            **{"cfg_" + k: v for k, v in c.items()})
     print("psnr", psnr)
 
 
