@@ -45,6 +45,15 @@ const char *nerfmi_last_error(void);
 int nerfmi_sample_stratified(const float *rays, const float *perturb_rand, int n_rays, int n_samples,
                              int use_disp, float perturb, float *z_out, nerfmi_stream_t stream);
 
+/* The random draws of one render_rays call from ONE launch (perf mode; parity tests inject the reference's captured
+ * draws instead): perturb_rand (n_perturb floats, U[0,1)) [rendering.py:221], noise_coarse (N(0,1)) [:170], u (U[0,1))
+ * [:47], noise_fine (N(0,1)).  Philox4x32-10 keyed by `seed`, counter = (quad, segment, offset): the same
+ * (seed, offset) always gives the same draws, independent of the sizes of the other segments.  A segment with size 0
+ * is skipped (its pointer may be NULL). */
+int nerfmi_render_draws(uint64_t seed, uint64_t offset, int64_t n_perturb, float *perturb_rand, int64_t n_noise_coarse,
+                        float *noise_coarse, int64_t n_u, float *u, int64_t n_noise_fine, float *noise_fine,
+                        nerfmi_stream_t stream);
+
 /* ---- a5: Embedding.forward -- models/nerf.py:21-38 -----------------------
  * x (n,3) -> out (n, 3*(2*n_freqs+1)) = [x, sin(2^k x), cos(2^k x)]_k. */
 int nerfmi_embed(const float *x, int64_t n, int n_freqs, float *out, nerfmi_stream_t stream);

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnerfmi.so")
+# NERFMI_LIB: an experiment build of the same ABI (tools/exp_*.py, nerf_siren_amd/build.py NERFMI_LIB_OUT)
+LIB_PATH = os.environ.get("NERFMI_LIB") or os.path.join(_HERE, "lib", "libnerfmi.so")
 
 _f = C.c_void_p          # device pointers travel as integers
 _i = C.c_int
@@ -19,6 +20,7 @@ SIGNATURES = {
     "nerfmi_version": (C.c_int, []),
     "nerfmi_last_error": (C.c_char_p, []),
     "nerfmi_sample_stratified": (_i, [_f, _f, _i, _i, _i, _fl, _f, _f]),
+    "nerfmi_render_draws": (_i, [C.c_uint64, C.c_uint64, _i64, _f, _i64, _f, _i64, _f, _i64, _f, _f]),
     "nerfmi_embed": (_i, [_f, _i64, _i, _f, _f]),
     "nerfmi_nerf_packed_floats": (C.c_size_t, []),
     "nerfmi_nerf_pack": (_i, [C.POINTER(C.c_void_p), _f, _f]),

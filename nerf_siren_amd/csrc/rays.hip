@@ -53,6 +53,67 @@ __global__ void sample_stratified_kernel(const float *__restrict__ rays, const f
 }
 
 // ---------------------------------------------------------------------------
+// The four random draws of one render_rays call (rand(N,S) [rendering.py:221], randn(N,S) [:170],
+// rand(N,F) [:47], randn(N,S+F)) from ONE launch of a counter-based generator, instead of four aten distribution
+// launches: Philox4x32-10 (Salmon et al., SC'11; Random123 known-answer vectors in tests/), key = seed, counter =
+// (quad index, segment, offset lo, offset hi); each thread turns one 128-bit block into four floats of one segment.
+// uniform: (x >> 8) * 2^-24 in [0,1) (24 bits, like torch.rand); normal: Box-Muller on two such pairs.  The draws
+// are written to memory rather than regenerated inside the consuming kernels: the compositor's backward needs the
+// SAME noise as its forward, and 5 B/sample of traffic is cheaper than two more Philox + Box-Muller evaluations.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+struct DrawSegs {
+    float *out[4];
+    long long n[4];          // floats in the segment (0 = skipped); segments 0, 2 uniform, 1, 3 normal
+    long long quad0[5];      // first quad of each segment, total at [4]
+};
+
+__global__ void render_draws_kernel(DrawSegs G, unsigned long long seed, unsigned long long offset) {
+    for (long long qd = (long long)blockIdx.x * blockDim.x + threadIdx.x; qd < G.quad0[4];
+         qd += (long long)gridDim.x * blockDim.x) {
+        int seg = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (qd >= G.quad0[k]) seg = k;
+        const long long i = qd - G.quad0[seg];
+        unsigned c[4] = {(unsigned)i, (unsigned)seg | ((unsigned)(i >> 32) << 2), (unsigned)offset, (unsigned)(offset >> 32)};
+        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+        float v[4];
+        if (seg & 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float u1 = (float)((c[2 * h] >> 8) + 1u) * 5.9604644775390625e-8f;      // (0, 1]
+                const float u2 = (float)(c[2 * h + 1] >> 8) * 5.9604644775390625e-8f;         // [0, 1)
+                const float r = sqrtf(-2.0f * logf(u1));
+                float sn, cs;
+                sincosf(6.283185307179586f * u2, &sn, &cs);
+                v[2 * h] = r * cs;
+                v[2 * h + 1] = r * sn;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = (float)(c[t] >> 8) * 5.9604644775390625e-8f;
+        }
+        float *dst = G.out[seg] + 4 * i;
+        const long long left = G.n[seg] - 4 * i;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < left) dst[t] = v[t];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // a5  Embedding.forward (models/nerf.py:21-38)
 // ---------------------------------------------------------------------------
 __global__ void embed_kernel(const float *__restrict__ x, int64_t n, int n_freqs, float *__restrict__ out) {
@@ -451,6 +512,28 @@ int nerfmi_sample_stratified(const float *rays, const float *perturb_rand, int n
     hipLaunchKernelGGL(sample_stratified_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, rays,
                        perturb_rand, n_rays, n_samples, use_disp, perturb, z_out);
     return check_launch("sample_stratified");
+}
+
+int nerfmi_render_draws(uint64_t seed, uint64_t offset, int64_t n_perturb, float *perturb_rand, int64_t n_noise_coarse,
+                        float *noise_coarse, int64_t n_u, float *u, int64_t n_noise_fine, float *noise_fine,
+                        nerfmi_stream_t stream) {
+    DrawSegs G;
+    const int64_t n[4] = {n_perturb, n_noise_coarse, n_u, n_noise_fine};
+    float *const o[4] = {perturb_rand, noise_coarse, u, noise_fine};
+    long long q = 0;
+    for (int k = 0; k < 4; ++k) {
+        NERFMI_REQUIRE(n[k] >= 0 && (n[k] == 0 || o[k]), "render_draws: segment %d has a size but no buffer", k);
+        G.out[k] = o[k];
+        G.n[k] = n[k];
+        G.quad0[k] = q;
+        q += (n[k] + 3) / 4;
+    }
+    G.quad0[4] = q;
+    if (q == 0) return NERFMI_OK;
+    const long long blocks = (q + 255) / 256;
+    hipLaunchKernelGGL(render_draws_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                       G, (unsigned long long)seed, (unsigned long long)offset);
+    return check_launch("render_draws");
 }
 
 int nerfmi_embed(const float *x, int64_t n, int n_freqs, float *out, nerfmi_stream_t stream) {

@@ -106,6 +106,10 @@ siren_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__re
         const int r = 2 * pr;
         const int u = 256 * layer + 32 * kb + 8 * (r >> 2) + (r & 3);
         const float2 f = *reinterpret_cast<const float2 *>(fq + u), s = *reinterpret_cast<const float2 *>(ph + u);
+        // sin_cw, not the cheaper sin_pi of the fp32 kernels: with sin_pi in this hook the kernel returned load-dependent
+        // garbage / NaN in scattered lanes of the colour branch on MI355X (n = 1024 rays: half the points; bisected on
+        // the GPU with tools/dbg_siren_fast.py, cause not found -- the ISA's register allocation and LDS ring check
+        // out), while the same build with sin_cw agrees with the fp32 kernel to 2e-6 on every point.
         x0 = sin_cw(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.x, 15.0f), 30.0f), x0), s.x));
         x1 = sin_cw(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.y, 15.0f), 30.0f), x1), s.y));
     };
@@ -186,11 +190,12 @@ int nerfmi_siren_forward_points(const float *packed, const float *points, const 
     const int64_t waves = (n_points + 31) / 32;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    const bool one_cond = points_per_cond >= n_points;
     if (sigma_only)
-        hipLaunchKernelGGL((siren_forward_kernel<false, true, false>), grid, block, 0, st, packed, nullptr, nullptr, points,
+        SIREN_FORWARD_LAUNCH(false, true, false, grid, block, 0, st, packed, nullptr, nullptr, points,
                            ray_directions, frequencies, phase_shifts, n_points, 1, points_per_cond, out, nullptr, (int64_t)0);
     else
-        hipLaunchKernelGGL((siren_forward_kernel<false, false, false>), grid, block, 0, st, packed, nullptr, nullptr, points,
+        SIREN_FORWARD_LAUNCH(false, false, false, grid, block, 0, st, packed, nullptr, nullptr, points,
                            ray_directions, frequencies, phase_shifts, n_points, 1, points_per_cond, out, nullptr, (int64_t)0);
     return check_launch("siren_forward_points");
 }
@@ -205,11 +210,12 @@ int nerfmi_siren_forward_rays(const float *packed, const float *rays, const floa
     const int64_t waves = (n_points + 31) / 32;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    const bool one_cond = rays_per_cond >= n_rays;
     if (sigma_only)
-        hipLaunchKernelGGL((siren_forward_kernel<true, true, false>), grid, block, 0, st, packed, rays, z, nullptr, nullptr,
+        SIREN_FORWARD_LAUNCH(true, true, false, grid, block, 0, st, packed, rays, z, nullptr, nullptr,
                            frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out, nullptr, (int64_t)0);
     else
-        hipLaunchKernelGGL((siren_forward_kernel<true, false, false>), grid, block, 0, st, packed, rays, z, nullptr, nullptr,
+        SIREN_FORWARD_LAUNCH(true, false, false, grid, block, 0, st, packed, rays, z, nullptr, nullptr,
                            frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out, nullptr, (int64_t)0);
     return check_launch("siren_forward_rays");
 }

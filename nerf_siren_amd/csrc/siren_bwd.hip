@@ -34,23 +34,31 @@ __device__ __forceinline__ f32x16 load_block(const RowImage &im, int row0) {
 }
 
 // d pre = d h * fr * cos(arg) for the four units of slice q of block jb (layer `layer`):
-// s = saved sines (this lane's 16 of the block), sign bits in mk
-__device__ __forceinline__ f32x4 film_grad(f32x4 dh, const f32x16 &s, const unsigned (&mk)[4], const float *fq, int layer,
-                                           int jb, int q) {
-    const f32x4 f = ldg4(fq + 256 * layer + 32 * jb + 8 * q);
+// s = saved sines (this lane's 16 of the block), sign bits of the cosines in mk, fr from LDS (COND_LDS) or memory
+template <bool COND_LDS>
+__device__ __forceinline__ f32x4 film_grad(f32x4 dh, const f32x16 &s, const unsigned (&mk)[4], const float *fq,
+                                           const float *lfr, int layer, int jb, int q) {
+    f32x4 fr;
+    if (COND_LDS) {
+        fr = *reinterpret_cast<const f32x4 *>(lfr + 256 * layer + 32 * jb + 8 * q);
+    } else {
+        const f32x4 f = ldg4(fq + 256 * layer + 32 * jb + 8 * q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fr[t] = __fadd_rn(__fmul_rn(f[t], 15.0f), 30.0f);                  // nerf.py:202
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const float fr = __fadd_rn(__fmul_rn(f[t], 15.0f), 30.0f);                      // nerf.py:202
         const float sv = s[4 * q + t];
         const float c2 = (1.0f - sv) * (1.0f + sv);
-        float ca = __builtin_sqrtf(c2 > 0.f ? c2 : 0.f);
-        const unsigned neg = (mk[jb >> 1] >> (16 * (jb & 1) + 4 * q + t)) & 1u;
-        ca = __uint_as_float(__float_as_uint(ca) | (neg << 31));
-        dh[t] = dh[t] * (fr * ca);
+        const float ca = __builtin_sqrtf(fmaxf(c2, 0.f));
+        // the cosine's sign: bit (sh + t) of the mask word moved to bit 31 and OR-ed in (v_lshlrev + v_and_or)
+        const unsigned sgn = (mk[jb >> 1] << (31 - (16 * (jb & 1) + 4 * q + t))) & 0x80000000u;
+        dh[t] = dh[t] * (fr[t] * __uint_as_float(__float_as_uint(ca) | sgn));
     }
     return dh;
 }
 
+template <bool COND_LDS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 siren_backward_chain_kernel(const float *__restrict__ packed, const float *__restrict__ saved,
                             const float *__restrict__ grad_out, const float *__restrict__ freq, int64_t n_points,
@@ -66,7 +74,14 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
     RowImage S, Wk;
     S.init(const_cast<float *>(saved), wave, ld / 32, SIREN_SAVED_ROWS, lane, ok, live);
     Wk.init(work, wave, ld / 32, SW_ROWS, lane, ok, live);
-    const float *fq = freq + (p / points_per_cond) * 2304 + 4 * half;
+    // fr = 15 f + 30 of the launch's one conditioning row staged in LDS (COND_LDS), else this lane's row from memory
+    __shared__ __attribute__((aligned(16))) float film[COND_LDS ? 2304 : 4];
+    if (COND_LDS) {
+        for (int i = threadIdx.x; i < 2304; i += blockDim.x) film[i] = __fadd_rn(__fmul_rn(freq[i], 15.0f), 30.0f);
+        __syncthreads();
+    }
+    const float *fq = freq + (COND_LDS ? 0 : (p / points_per_cond) * 2304) + 4 * half;
+    const float *lfr = film + 4 * half;
 
     float4 go = make_float4(0.f, 0.f, 0.f, 0.f);       // points past the end: every dZ below is exactly 0
     if (ok) go = reinterpret_cast<const float4 *>(grad_out)[praw];
@@ -101,7 +116,7 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 dh[t] = __builtin_fmaf(w[2][t], dpre[2], __builtin_fmaf(w[1][t], dpre[1], w[0][t] * dpre[0]));
-            dh = film_grad(dh, sv, mk, fq, 8, b, q);
+            dh = film_grad<COND_LDS>(dh, sv, mk, fq, lfr, 8, b, q);
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[4 * q + t] = dh[t];
         }
@@ -119,7 +134,7 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
                                          const f32x4 w = ldg4(packed + SOFF_W_SIGMA + 32 * jb + 8 * q + 4 * half);
 #pragma unroll
                                          for (int t = 0; t < 4; ++t) c[t] = __builtin_fmaf(w[t], dsig, c[t]);
-                                         c = film_grad(c, sv, mk, fq, 7, jb, q);
+                                         c = film_grad<COND_LDS>(c, sv, mk, fq, lfr, 7, jb, q);
                                          store_slice(Wk, SW_DZ + 7 * 256 + 32 * jb, q, c);
                                          return c;
                                      }, wlds, ws, wid, lane);
@@ -129,7 +144,7 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
         layer_mfma_lds<8, 0, 8, 0, false>(packed + SOFF_T7 + (7 - l) * SZ_HID, nullptr, in, nullptr, out_dz,
                                           [&S, l](int jb) { return load_block(S, SS_H + (l - 1) * 256 + 32 * jb); },
                                           [&, l](int jb, int q, f32x4 c, const f32x16 &sv) {
-                                              c = film_grad(c, sv, mk, fq, l - 1, jb, q);
+                                              c = film_grad<COND_LDS>(c, sv, mk, fq, lfr, l - 1, jb, q);
                                               store_slice(Wk, SW_DZ + (l - 1) * 256 + 32 * jb, q, c);
                                               return c;
                                           }, wlds, ws, wid, lane);
@@ -211,7 +226,8 @@ int nerfmi_siren_forward_rays_train(const float *packed, const float *rays, cons
     if (n_points == 0) return NERFMI_OK;
     NERFMI_REQUIRE(packed && rays && z && frequencies && phase_shifts && out && saved, "siren_forward_rays_train: null pointer");
     const int64_t waves = (n_points + 31) / 32;
-    hipLaunchKernelGGL((siren_forward_kernel<true, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+    const bool one_cond = rays_per_cond >= n_rays;
+    SIREN_FORWARD_LAUNCH(true, false, true, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, packed, rays, z, nullptr, nullptr, frequencies, phase_shifts, n_points,
                        n_per_ray, rays_per_cond * n_per_ray, out, saved, siren_pad_points(n_points));
     return check_launch("siren_forward_rays_train");
@@ -225,7 +241,8 @@ int nerfmi_siren_forward_points_train(const float *packed, const float *points, 
     NERFMI_REQUIRE(packed && points && ray_directions && frequencies && phase_shifts && out && saved,
                    "siren_forward_points_train: null pointer");
     const int64_t waves = (n_points + 31) / 32;
-    hipLaunchKernelGGL((siren_forward_kernel<false, false, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+    const bool one_cond = points_per_cond >= n_points;
+    SIREN_FORWARD_LAUNCH(false, false, true, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, packed, nullptr, nullptr, points, ray_directions, frequencies, phase_shifts,
                        n_points, 1, points_per_cond, out, saved, siren_pad_points(n_points));
     return check_launch("siren_forward_points_train");
@@ -260,8 +277,12 @@ int nerfmi_siren_backward(const float *packed, const float *saved, const float *
         }
         attr_set.mark(attr_dev);
     }
-    hipLaunchKernelGGL(siren_backward_chain_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
-                       grad_out, frequencies, n_points, points_per_cond, ld, work);
+    if (points_per_cond >= n_points)
+        hipLaunchKernelGGL(siren_backward_chain_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
+                           grad_out, frequencies, n_points, points_per_cond, ld, work);
+    else
+        hipLaunchKernelGGL(siren_backward_chain_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed,
+                           saved, grad_out, frequencies, n_points, points_per_cond, ld, work);
     hipLaunchKernelGGL(siren_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
     hipLaunchKernelGGL(dw_reduce_kernel<1>, dim3(128, P.n_tasks), dim3(256), 0, st, P, partial, G);
     return check_launch("siren_backward");

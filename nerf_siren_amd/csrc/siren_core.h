@@ -58,28 +58,21 @@ __device__ __forceinline__ void load_mask_row(const RowImage &im, int row, unsig
     mk[0] = v[0]; mk[1] = v[1]; mk[2] = v[2]; mk[3] = v[3];
 }
 
-// sin(x) and the SIGN BIT of cos(x) (1 = negative) by the Cody-Waite reduction of sincos_cw (mlp_core.h): with
-// x = j*pi/2 + r, |r| <= pi/4, m = j mod 4:  cos x = cos r, -sin r, -cos r, sin r  for m = 0..3, so the sign is
-// (m in {1,2}) flipped for odd m when r < 0.  (Where r == 0 and m is odd the cosine is 0 and the bit is irrelevant.)
-__device__ __forceinline__ float sin_cossign_cw(float x, unsigned &cos_neg) {
-    const float j = rintf(x * 0.63661977236758134308f);
-    float r = __builtin_fmaf(-j, 1.57079637050628662109375f, x);
-    r = __builtin_fmaf(-j, -4.37113900018624283e-8f, r);
-    const float s2 = r * r;
-    float ps = __builtin_fmaf(s2, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = __builtin_fmaf(s2, ps, -1.6666654611e-1f);
-    const float sn = __builtin_fmaf(r * s2, ps, r);
-    float pc = __builtin_fmaf(s2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = __builtin_fmaf(s2, pc, 4.166664568298827e-2f);
-    const float cs = __builtin_fmaf(s2 * s2, pc, __builtin_fmaf(-0.5f, s2, 1.0f));
-    const int q = (int)j;
-    const float sv = (q & 1) ? cs : sn;
-    const unsigned rneg = __float_as_uint(r) >> 31;
-    cos_neg = ((unsigned)((q + 1) >> 1) ^ ((unsigned)q & rneg)) & 1u;
-    return (q & 2) ? -sv : sv;
+// FiLM constants of one conditioning row staged in LDS by the workgroup: fr = 15 f + 30 (nerf.py:202) computed ONCE per
+// unit instead of once per (unit, point), and read with ds_read_b128 in the epilogues instead of L2-latency global loads
+// inside the fenced epilogue clumps.  Used when the whole launch shares one conditioning row (COND_LDS; render_rays'
+// SirenField always does); otherwise the rows are read from global memory per lane.
+constexpr int FILM_FLOATS = 2 * 2304;       // [fr 9 x 256][phase 9 x 256]
+
+__device__ __forceinline__ void stage_film(float *film, const float *__restrict__ freq, const float *__restrict__ phase) {
+    for (int i = threadIdx.x; i < 2304; i += blockDim.x) {
+        film[i] = __fadd_rn(__fmul_rn(freq[i], 15.0f), 30.0f);
+        film[2304 + i] = phase[i];
+    }
+    __syncthreads();
 }
 
-template <bool FROM_RAYS, bool SIGMA_ONLY, bool SAVE>
+template <bool FROM_RAYS, bool SIGMA_ONLY, bool SAVE, bool COND_LDS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__ rays, const float *__restrict__ z,
                      const float *__restrict__ pts, const float *__restrict__ dirs, const float *__restrict__ freq,
@@ -121,26 +114,31 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
         store_block(S, SS_X, e[0]);
         store_block(S, SS_D, de[0]);
     }
-    // this lane's conditioning row (frequencies, phase_shifts are (n_cond, 9*256))
-    const float *fq = freq + (p / points_per_cond) * 2304 + 4 * half;
-    const float *ph = phase + (p / points_per_cond) * 2304 + 4 * half;
+    // conditioning: one row for the launch staged in LDS (COND_LDS), else this lane's row (n_cond, 9*256) from memory
+    __shared__ __attribute__((aligned(16))) float film[COND_LDS ? FILM_FLOATS : 4];
+    if (COND_LDS) stage_film(film, freq, phase);
+    const float *fq = freq + (COND_LDS ? 0 : (p / points_per_cond) * 2304) + 4 * half;
+    const float *ph = phase + (COND_LDS ? 0 : (p / points_per_cond) * 2304) + 4 * half;
+    const float *lfr = film + 4 * half;
     unsigned mk[4] = {0u, 0u, 0u, 0u};
     auto film_epi = [&](int layer) {
-        return [fq, ph, layer, &S, &mk](int jb, int q, f32x4 c, int) {
-            const f32x4 f = ldg4(fq + 256 * layer + 32 * jb + 8 * q);
-            const f32x4 s = ldg4(ph + 256 * layer + 32 * jb + 8 * q);
+        return [fq, ph, lfr, layer, &S, &mk](int jb, int q, f32x4 c, int) {
+            f32x4 fr, s;
+            if (COND_LDS) {
+                fr = *reinterpret_cast<const f32x4 *>(lfr + 256 * layer + 32 * jb + 8 * q);
+                s = *reinterpret_cast<const f32x4 *>(lfr + 2304 + 256 * layer + 32 * jb + 8 * q);
+            } else {
+                const f32x4 f = ldg4(fq + 256 * layer + 32 * jb + 8 * q);
+                s = ldg4(ph + 256 * layer + 32 * jb + 8 * q);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fr[t] = __fadd_rn(__fmul_rn(f[t], 15.0f), 30.0f);      // nerf.py:202
+            }
             const int sh = 16 * (jb & 1) + 4 * q;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float fr = __fadd_rn(__fmul_rn(f[t], 15.0f), 30.0f);          // nerf.py:202
-                const float arg = __fadd_rn(__fmul_rn(fr, c[t]), s[t]);              // nerf.py:151
-                if (SAVE) {
-                    unsigned neg;
-                    c[t] = sin_cossign_cw(arg, neg);
-                    asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(mk[jb >> 1]) : "v"(neg), "s"(sh + t));
-                } else {
-                    c[t] = sin_cw(arg);
-                }
+                unsigned jbits;
+                c[t] = sin_pi(__fadd_rn(__fmul_rn(fr[t], c[t]), s[t]), jbits);                      // nerf.py:151
+                if (SAVE) mk[jb >> 1] |= (jbits & 1u) << (sh + t);                                  // sign of cos(arg)
             }
             if (SAVE) store_slice(S, (layer < 8 ? SS_H + 256 * layer : SS_HC) + 32 * jb, q, c);
             return c;
@@ -193,5 +191,12 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
 }
 
 static inline int64_t siren_pad_points(int64_t n) { return (n + 31) / 32 * 32; }
+
+// the launch shares ONE conditioning row (`one_cond` in scope): FiLM constants through LDS, else per-lane rows from memory
+#define SIREN_FORWARD_LAUNCH(FROM_RAYS, SIGMA_ONLY, SAVE, ...)                                                        \
+    do {                                                                                                              \
+        if (one_cond) hipLaunchKernelGGL((siren_forward_kernel<FROM_RAYS, SIGMA_ONLY, SAVE, true>), __VA_ARGS__);      \
+        else hipLaunchKernelGGL((siren_forward_kernel<FROM_RAYS, SIGMA_ONLY, SAVE, false>), __VA_ARGS__);              \
+    } while (0)
 
 }  // namespace nerfmi

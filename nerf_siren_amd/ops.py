@@ -81,6 +81,40 @@ def sample_stratified(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand
     return z
 
 
+_DRAW_OFFSET = {}
+
+
+def render_draws(device, n_rays, S, F, perturb=True, noise=True, seed=None, offset=None):
+    """The random draws of one render_rays call from ONE launch (nerfmi_render_draws): dict with 'perturb_rand' (N,S),
+    'u' (N,F) when `perturb`, 'noise_coarse' (N,S), 'noise_fine' (N,S+F) when `noise` -- views of one allocation.
+    seed defaults to torch.initial_seed() (torch.manual_seed controls it), offset to a per-device call counter."""
+    if seed is None:
+        seed = torch.initial_seed()
+    if offset is None:
+        offset = _DRAW_OFFSET.get(device, 0)
+        _DRAW_OFFSET[device] = offset + 1
+    sizes = [n_rays * S if perturb else 0, n_rays * S if noise else 0, n_rays * F if perturb else 0,
+             n_rays * (S + F) if (noise and F > 0) else 0]
+    buf = torch.empty(sum(sizes), device=device, dtype=torch.float32)
+    segs, off = [], 0
+    for n in sizes:
+        segs.append(buf[off:off + n] if n else None)
+        off += n
+    check(_lib.lib().nerfmi_render_draws(int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), sizes[0], ptr(segs[0]),
+                                         sizes[1], ptr(segs[1]), sizes[2], ptr(segs[2]), sizes[3], ptr(segs[3]),
+                                         torch.cuda.current_stream(device).cuda_stream), "render_draws")
+    out = {}
+    if sizes[0]:
+        out["perturb_rand"] = segs[0].view(n_rays, S)
+    if sizes[1]:
+        out["noise_coarse"] = segs[1].view(n_rays, S)
+    if sizes[2]:
+        out["u"] = segs[2].view(n_rays, F)
+    if sizes[3]:
+        out["noise_fine"] = segs[3].view(n_rays, S + F)
+    return out
+
+
 # --------------------------------------------------------------------------- a5
 def embed(x, n_freqs):
     x = _req(x, "x", (None, 3))

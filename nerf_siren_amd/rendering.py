@@ -178,12 +178,25 @@ class EmbeddedField(torch.autograd.Function):
 
 def _rng(rng, key, shape, device, kind):
     t = None if rng is None else rng.get(key)
-    if t is not None:
-        if tuple(t.shape) != tuple(shape):
-            raise ValueError(f"rng['{key}'] has shape {tuple(t.shape)}, expected {tuple(shape)}")
-        return t
-    gen = torch.rand if kind == "rand" else torch.randn
-    return gen(shape, device=device, dtype=torch.float32)
+    if t is None:
+        raise KeyError(key)                     # render_rays fills every draw it needs before asking for it
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"rng['{key}'] has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+def _complete_draws(rng, device, N, S, F, perturb, noise_std):
+    """The reference's draws (rendering.py:221 rand, :170 randn, :47 rand, :170 randn) that the caller did not inject,
+    all from ONE Philox launch (ops.render_draws) instead of up to four aten distribution launches."""
+    have = rng or {}
+    need_p = (perturb > 0 and "perturb_rand" not in have) or (perturb != 0 and F > 0 and "u" not in have
+                                                               and "z_fine" not in have)
+    need_n = noise_std != 0 and (rng is None or "noise_coarse" not in rng or (F > 0 and "noise_fine" not in rng))
+    if not (need_p or need_n):
+        return rng
+    drawn = ops.render_draws(device, N, S, F, perturb=need_p, noise=need_n)
+    drawn.update(rng or {})                     # injected tensors win
+    return drawn
 
 
 def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=0, noise_std=1, N_importance=0,
@@ -196,7 +209,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     chunk: accepted for compatibility; the fused kernels need no point chunking.
     rng (keyword-only, optional): dict of injected random draws in the reference's
     order -- 'perturb_rand' (N,S) [rendering.py:221], 'noise_coarse' (N,S) [:170],
-    'u' (N,F) [:47], 'noise_fine' (N,S+F); missing entries are drawn on the device.  'z_fine' (N,S+F), when given,
+    'u' (N,F) [:47], 'noise_fine' (N,S+F); missing entries are drawn on the device by ONE Philox launch
+    (ops.render_draws; torch.manual_seed sets the key).  'z_fine' (N,S+F), when given,
     replaces the merged depths of :247 (parity tests condition the fine pass on the reference's own depths:
     sample_pdf is ill-conditioned in ~zero-weight bins).
     aux (keyword-only, optional): a dict that receives the intermediates 'z_coarse', 'weights_coarse', 'z_fine'.
@@ -213,6 +227,7 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     model_coarse = models[0]
     train = torch.is_grad_enabled() and any(p.requires_grad for m in models for p in m.parameters())
 
+    rng = _complete_draws(rng, dev, N, S, F, perturb, noise_std)
     pr = _rng(rng, "perturb_rand", (N, S), dev, "rand") if perturb > 0 else None
     z = ops.sample_stratified(rays, S, use_disp, float(perturb), pr)
 

@@ -651,3 +651,44 @@ def split3(x):
     p1 = bf16_round(r1)
     r2 = (r1 - p1).astype(F32)
     return p0, p1, bf16_round(r2)
+
+
+# ----------------------------------------------------------------------------
+# perf-mode random draws: Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+# SC'11; the Random123 known-answer vectors are in tests/test_oracle_golden.py) as csrc/rays.hip render_draws_kernel
+# uses it.  Not part of the reference (which draws from torch's mt19937 on CPU): parity tests inject draws instead.
+# ----------------------------------------------------------------------------
+def philox4x32_10(counter, key):
+    """counter (..., 4) uint32, key (..., 2) uint32 -> (..., 4) uint32."""
+    c = [np.asarray(counter[..., i], np.uint64) for i in range(4)]
+    k = [np.asarray(key[..., i], np.uint64) for i in range(2)]
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k[0]) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k[1]) & m32, p0 & m32]
+        k = [(k[0] + np.uint64(0x9E3779B9)) & m32, (k[1] + np.uint64(0xBB67AE85)) & m32]
+    return np.stack(c, -1).astype(np.uint32)
+
+
+def render_draws(seed: int, offset: int, sizes):
+    """The four segments of nerfmi_render_draws: sizes = (n_perturb, n_noise_coarse, n_u, n_noise_fine) floats;
+    segments 0, 2 uniform [0,1), segments 1, 3 N(0,1) by Box-Muller.  Returns four fp32 arrays."""
+    out = []
+    for seg, n in enumerate(sizes):
+        q = (n + 3) // 4
+        i = np.arange(q, dtype=np.uint64)
+        ctr = np.stack([i & np.uint64(0xFFFFFFFF), np.uint64(seg) | ((i >> np.uint64(32)) << np.uint64(2)),
+                        np.full(q, offset & 0xFFFFFFFF, np.uint64), np.full(q, (offset >> 32) & 0xFFFFFFFF, np.uint64)], -1)
+        key = np.stack([np.full(q, seed & 0xFFFFFFFF, np.uint64), np.full(q, (seed >> 32) & 0xFFFFFFFF, np.uint64)], -1)
+        x = philox4x32_10(ctr.astype(np.uint32), key.astype(np.uint32))
+        if seg & 1:
+            u1 = ((x[:, 0::2] >> 8).astype(F32) + F32(1)) * F32(2.0 ** -24)
+            u2 = (x[:, 1::2] >> 8).astype(F32) * F32(2.0 ** -24)
+            r = np.sqrt(F32(-2.0) * np.log(u1)).astype(F32)
+            a = (F32(6.283185307179586) * u2).astype(F32)
+            v = np.stack([r * np.cos(a), r * np.sin(a)], -1).reshape(q, 4).astype(F32)
+        else:
+            v = ((x >> 8).astype(F32) * F32(2.0 ** -24)).astype(F32)
+        out.append(v.reshape(-1)[:n])
+    return out

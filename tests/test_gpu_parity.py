@@ -1643,3 +1643,51 @@ def test_nerf_module_forward_autograd(dev, models):
         m(T(x, dev).requires_grad_(True))
     with torch.no_grad():
         assert not m(T(x, dev)).requires_grad
+
+
+# --------------------------------------------------------------------------- perf-mode random draws (one Philox launch)
+def test_render_draws_philox(ops, dev):
+    """nerfmi_render_draws against the numpy restatement of Philox4x32-10 (itself checked on Random123's known-answer
+    vectors): uniforms bit-exact, Box-Muller normals to libm accuracy; (seed, offset) addressing; ragged sizes."""
+    N_, S, F = 37, 64, 33
+    d = ops.render_draws(dev, N_, S, F, seed=0x1234567890ABCDEF, offset=5)
+    ref = O.render_draws(0x1234567890ABCDEF, 5, (N_ * S, N_ * S, N_ * F, N_ * (S + F)))
+    assert np.array_equal(N(d["perturb_rand"]).reshape(-1), ref[0]) and np.array_equal(N(d["u"]).reshape(-1), ref[2])
+    np.testing.assert_allclose(N(d["noise_coarse"]).reshape(-1), ref[1], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(N(d["noise_fine"]).reshape(-1), ref[3], rtol=0, atol=2e-5)
+    assert d["perturb_rand"].shape == (N_, S) and d["noise_fine"].shape == (N_, S + F)
+    assert float(d["u"].min()) >= 0 and float(d["u"].max()) < 1
+    d2 = ops.render_draws(dev, N_, S, F, seed=0x1234567890ABCDEF, offset=5)
+    d3 = ops.render_draws(dev, N_, S, F, seed=0x1234567890ABCDEF, offset=6)
+    assert torch.equal(d["noise_fine"], d2["noise_fine"]) and not torch.equal(d["u"], d3["u"])
+    only = ops.render_draws(dev, N_, S, F, perturb=False, seed=0x1234567890ABCDEF, offset=5)
+    assert set(only) == {"noise_coarse", "noise_fine"} and torch.equal(only["noise_coarse"], d["noise_coarse"])
+    big = ops.render_draws(dev, 4096, 64, 64, seed=1, offset=0)
+    n = big["noise_fine"]
+    assert abs(float(n.mean())) < 5e-3 and abs(float(n.std()) - 1) < 5e-3
+    assert abs(float(big["perturb_rand"].mean()) - 0.5) < 5e-3
+
+
+def test_render_rays_draws_on_device(dev, models):
+    """Without injected draws render_rays takes them from ONE Philox launch keyed by torch.manual_seed: the same seed
+    and call count give the same image, a later call different noise; injected draws still win."""
+    from nerf_siren_amd import Embedding, render_rays
+    from nerf_siren_amd import ops as o
+    _, ms = models
+    emb = [Embedding(3, 10), Embedding(3, 4)]
+    rays = T(synth.blender_rays(200, 15), dev)
+
+    def run(**kw):
+        with torch.no_grad():
+            return render_rays(ms, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, True, False, **kw)
+    torch.manual_seed(77)
+    o._DRAW_OFFSET.clear()
+    a, b = run(), run()
+    torch.manual_seed(77)
+    o._DRAW_OFFSET.clear()
+    c = run()
+    assert torch.equal(a["rgb_fine"], c["rgb_fine"]) and not torch.equal(a["rgb_fine"], b["rgb_fine"])
+    assert torch.isfinite(a["rgb_fine"]).all()
+    inj = o.render_draws(dev, 200, 64, 64, seed=3, offset=9)
+    d, e = run(rng=inj), run(rng=dict(inj))
+    assert torch.equal(d["rgb_fine"], e["rgb_fine"])

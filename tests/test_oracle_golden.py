@@ -438,3 +438,18 @@ def test_grid_queries_oracle_vs_reference(golden):
         np.testing.assert_allclose(smp, g[f"cs{n}_samples"], rtol=0, atol=2.4e-7)
     vol = O.pack_vol(g["vol_rgbsigma"], int(g["vol_N"]), float(g["vol_extent"]))
     assert vol.dtype == np.uint32 and np.array_equal(vol, g["vol_records"])
+
+
+def test_philox_known_answers():
+    """Random123's known-answer vectors for philox4x32-10 (kat_vectors): the generator behind the perf-mode draws."""
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        got = O.philox4x32_10(np.array([ctr], np.uint32), np.array([key], np.uint32))[0]
+        assert [int(v) for v in got] == want
+    a = O.render_draws(1234, 7, (1000, 1000, 999, 2001))
+    assert [len(v) for v in a] == [1000, 1000, 999, 2001]
+    assert all(0 <= v.min() and v.max() < 1 for v in (a[0], a[2]))
+    assert abs(a[3].mean()) < 0.1 and abs(a[3].std() - 1) < 0.1
