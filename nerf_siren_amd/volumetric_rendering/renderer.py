@@ -4,7 +4,8 @@ Training: when grad is enabled and the planes or the decoder require grad, the w
 node (`_RenderFn`) whose backward is marcher(fine) -> unify^-1 -> marcher(coarse) -> decoder/tri-plane scatter
 (csrc/eg3d_bwd.hip); depths carry no gradient, as in the reference (renderer.py:201 no_grad).
 rendering_options may carry two extra keys to inject the reference's random draws (parity tests):
-'rng_stratified' (N,M,S,1) = the rand_like of sample_stratified, 'rng_importance' (N*M,F) = the rand of sample_pdf.
+'rng_stratified' (N,M,S,1) = the rand_like of sample_stratified, 'rng_importance' (N*M,F) = the rand of sample_pdf;
+'aux' (a dict) receives the sampled depths of an inference call.
 """
 import weakref
 
@@ -168,6 +169,8 @@ class ImportanceRenderer(torch.nn.Module):
         all_d, all_c, all_s = eg3d_ops.unify(depths_coarse, cc, sc, depths_fine, colors_fine.reshape(N * M, F, 3),
                                              dens_fine.reshape(N * M, F))
         rgb_final, depth_final, _, wsum = eg3d_ops.march(all_c, all_s, all_d, wb)
+        if isinstance(opts.get('aux'), dict):        # test hook: the sampled depths (parity tests condition on them)
+            opts['aux'].update(depths_coarse=depths_coarse, depths_fine=depths_fine, all_depths=all_d)
         v = lambda t, c: t.view(N, M, c)
         return (v(rgb_coarse, 3), v(depth_coarse, 1), v(wsum_coarse, 1), v(rgb_final, 3), v(depth_final, 1), v(wsum, 1))
 

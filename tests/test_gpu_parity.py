@@ -726,23 +726,31 @@ def test_eg3d_importance_and_unify(golden, dev):
 
 
 def test_eg3d_forward(golden, dev, osg):
+    """ImportanceRenderer.forward against the reference (g12) and the oracle.  Coarse outputs: 1e-4 on every ray.
+    Fine outputs: 1e-4 on every ray whose 64 importance depths agree with the oracle's; the 100x bound applies only to
+    rays where a depth moved (sample_pdf's conditioning, as in the NeRF path), and their rate is bounded."""
     from nerf_siren_amd import ImportanceRenderer
     g = golden("g12_eg3d_forward")
     planes = T(synth.triplanes(6, res=64), dev)
-    opts = dict(synth.EG3D_OPTIONS, rng_stratified=T(g["rand_strat"], dev), rng_importance=T(g["u"], dev))
+    aux = {}
+    opts = dict(synth.EG3D_OPTIONS, rng_stratified=T(g["rand_strat"], dev), rng_importance=T(g["u"], dev), aux=aux)
     with torch.no_grad():
         res = ImportanceRenderer()(planes, osg, T(g["ray_o"][None], dev), T(g["ray_d"][None], dev), opts)
     ref = EO.importance_renderer(synth.triplanes(6, res=64), synth.osg_params(4), g["ray_o"][None], g["ray_d"][None],
                                  synth.EG3D_OPTIONS, g["rand_strat"], g["u"])
+    assert np.array_equal(N(aux["depths_coarse"]).reshape(50, 64), ref[6]["depths_coarse"].reshape(50, 64))
+    dz = np.abs(N(aux["depths_fine"]).reshape(50, 64) - ref[6]["depths_fine"].reshape(50, 64)).max(-1)
+    moved = dz > 1e-5 * 9.9
+    print(f"EG3D forward: rays with a moved importance depth {moved.mean():.3f}")
+    assert moved.mean() <= 0.25, moved.mean()
     for k, v, o in zip(("rgb_c", "depth_c", "op_c", "rgb_f", "depth_f", "op_f"), res, ref[:6]):
         v = N(v)
         assert v.shape == g[k].shape
         tol = 1e-4 * (9.9 if "depth" in k else 1.0)
         for target in (g[k], o):
             err = np.abs(v - target).reshape(50, -1).max(-1)
-            assert (err <= tol).mean() >= 0.9 and err.max() <= 100 * tol, (k, err.max())
-            if k.endswith("_c"):
-                assert err.max() <= tol, (k, err.max())
+            loose = moved & k.endswith("_f")
+            assert np.all(err[~loose] <= tol) and np.all(err <= 100 * tol), (k, err.max(), err[~loose].max())
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -911,20 +919,28 @@ def test_nerf_mlp_bf16x3_matches_fp32(ops, dev, models, n_rays, P):
 
 
 def test_render_rays_bf16x3(golden, dev, models):
+    """The opt-in split-bf16 math behind render_rays against the reference: same conditioned rule as the fp32 path
+    (strict 1e-4 wherever the merged depths agree with the reference's, 100x only on rays whose depths moved)."""
     import nerf_siren_amd
+    from nerf_siren_amd import Embedding, render_rays
     g = golden("g7_blender_test_time")
     params, ms = models
     nerf_siren_amd.set_math("bf16x3")
+    aux = {}
     try:
-        res = _run_hip(g, dev, ms)
+        with torch.no_grad():
+            res = render_rays(ms, [Embedding(3, 10), Embedding(3, 4)], T(g["rays"], dev), int(g["S"]), False, 0.0, 0.0,
+                              int(g["F"]), 1024 * 32, bool(g["white_back"]), True, aux=aux)
     finally:
         nerf_siren_amd.set_math("fp32")
+    n = g["rays"].shape[0]
+    moved = np.abs(N(aux["z_fine"]) - g["mid_sort_out"]).max(-1) > 1e-5 * 4.0
+    assert moved.mean() <= 0.5, moved.mean()                 # deterministic mode: the u = 1.0 edge (SURVEY section 7)
     for k in res:
-        err = np.abs(N(res[k]) - g["out_" + k]).reshape(g["rays"].shape[0], -1).max(-1)
+        err = np.abs(N(res[k]) - g["out_" + k]).reshape(n, -1).max(-1)
         tol = 1e-4 * (4.0 if "depth" in k else 1.0)
-        assert (err <= tol).mean() >= 0.65 and err.max() <= 100 * tol, (k, err.max())
-        if "coarse" in k:
-            assert err.max() <= tol
+        loose = moved & ("fine" in k)
+        assert np.all(err[~loose] <= tol) and np.all(err <= 100 * tol), (k, err.max())
 
 
 # --------------------------------------------------------------------------- harness (callers of the path)

@@ -453,3 +453,32 @@ def test_philox_known_answers():
     assert [len(v) for v in a] == [1000, 1000, 999, 2001]
     assert all(0 <= v.min() and v.max() < 1 for v in (a[0], a[2]))
     assert abs(a[3].mean()) < 0.1 and abs(a[3].std() - 1) < 0.1
+
+
+def test_png_gif_round_trip(tmp_path):
+    """eval.py:185-194 output formats (imageio.imwrite png, imageio.mimsave gif at 30 fps), written with the standard
+    library only: a decoder gets back exactly the pixels that were written (PNG) / their 3-3-2 palette images (GIF)."""
+    from nerf_siren_amd import io_utils as IO
+    rng = np.random.default_rng(0)
+    pred = rng.random((23, 17, 3)).astype(np.float32)
+    img = IO.to_uint8(pred)
+    assert img.dtype == np.uint8 and np.array_equal(img, (pred * 255).astype(np.uint8))
+    for a in (img, img[:, :, 0], rng.integers(0, 256, (9, 31, 4), dtype=np.uint8)):
+        f = str(tmp_path / "a.png")
+        IO.imwrite_png(f, a)
+        assert np.array_equal(IO.imread_png(f), a)
+        assert open(f, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    frames = [IO.to_uint8(rng.random((40, 56, 3))) for _ in range(3)]
+    yy, xx = np.mgrid[0:40, 0:56]
+    frames.append(np.stack([xx * 4 % 256, yy * 6 % 256, (xx + yy) * 2 % 256], -1).astype(np.uint8))   # compressible
+    f = str(tmp_path / "scene.gif")
+    IO.mimsave_gif(f, frames, fps=30)
+    got, delay = IO.mimread_gif(f)
+    assert delay == 3 and len(got) == len(frames)                 # round(100 / 30) hundredths of a second
+    for a, b in zip(frames, got):
+        assert np.array_equal(IO.PALETTE_332[IO._palette_332(a)], b)
+    big = [rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)]    # forces LZW dictionary resets
+    IO.mimsave_gif(f, big)
+    assert np.array_equal(IO.PALETTE_332[IO._palette_332(big[0])], IO.mimread_gif(f)[0][0])
+    with pytest.raises(TypeError):
+        IO.imwrite_png(str(tmp_path / "b.png"), pred)

@@ -1,15 +1,34 @@
 #!/bin/bash
-# GPU box: kernel-trace stats + PMC passes (one counter group per run, never combined with traces) for the training
-# and the inference step.  Outputs under gpurun_out/; summarise with tools/pmc_summary.py and copy into profiles/.
+# GPU box: kernel-trace stats + PMC passes (one counter group per run, never combined with traces) for the NeRF training /
+# inference steps, the FiLM-SIREN training / inference steps and the EG3D renderer.  Outputs under gpurun_out/prof_r02/;
+# summarise with tools/pmc_summary.py and copy into profiles/ (tools/collect_profiles.sh does the copying at the end into
+# gpurun_out/prof_r02/summary/, which is what gets committed as profiles/r02_*).
+# usage: gpurun --timeout 1100 -- bash tools/collect_profiles.sh
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rm -rf gpurun_out/prof_train gpurun_out/prof_infer gpurun_out/pmc_train gpurun_out/pmc_infer
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -o t -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-psnr --no-opt-in > gpurun_out/train_prof.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_infer -o t -- python3 bench.py --mode infer --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/infer_prof.log 2>&1
-for mode in train infer; do
-  for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum"; do
-    d=gpurun_out/pmc_$mode/$(echo $c | tr ' ' '_')
-    rocprofv3 --pmc $c --output-format csv -d $d -o p -- python3 bench.py --mode $mode --steps 3 --warmup 2 --no-cpu-baseline --no-psnr --no-opt-in > gpurun_out/pmc_$mode.log 2>&1
-    echo "pmc $mode $c done"
+O=gpurun_out/prof_r02
+rm -rf $O && mkdir -p $O/summary
+COMMON="--steps 20 --warmup 5 --no-cpu-baseline --no-psnr --no-opt-in --no-extra"
+run_trace() {   # name, bench args
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$1 -o t -- python3 bench.py $COMMON $2 > $O/trace_$1.log 2>&1
+  cp $O/trace_$1/*/t_kernel_stats.csv $O/summary/r02_$1_kernel_stats.csv 2>/dev/null || cp $(find $O/trace_$1 -name "t_kernel_stats.csv" | head -1) $O/summary/r02_$1_kernel_stats.csv
+  grep -o '"ms_per_step": [0-9.]*' $O/trace_$1.log | head -1 | sed "s/^/$1 /"
+}
+run_trace train "--mode train"
+run_trace infer "--mode infer"
+run_trace siren_train "--field siren --mode train"
+run_trace siren_infer "--field siren --mode infer"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_eg3d -o t -- python3 tools/bench_eg3d.py > $O/trace_eg3d.log 2>&1
+cp $(find $O/trace_eg3d -name "t_kernel_stats.csv" | head -1) $O/summary/r02_eg3d_kernel_stats.csv
+echo "traces done"
+PMC="--steps 3 --warmup 2 --no-cpu-baseline --no-psnr --no-opt-in --no-extra"
+for cfg in "train:--mode train" "infer:--mode infer" "siren_train:--field siren --mode train" "siren_infer:--field siren --mode infer"; do
+  name=${cfg%%:*}; args=${cfg#*:}
+  for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
+    d=$O/pmc_$name/$(echo $c | tr ' ' '_')
+    rocprofv3 --pmc $c --output-format csv -d $d -o p -- python3 bench.py $PMC $args > $O/pmc_$name.log 2>&1
+    echo "pmc $name $c done"
   done
+  python3 tools/pmc_summary.py $O/pmc_$name $O/summary/r02_pmc_$name.json > $O/summary/r02_pmc_$name.txt
 done
+echo "all done"; ls $O/summary
