@@ -408,7 +408,7 @@ def main():
             pass
         return None
     if siren:
-        traffic = pmc_traffic("siren_forward_kernel<true, false, true>" if train else "siren_forward_kernel<true, false, false>")
+        traffic = pmc_traffic("siren_forward_kernel<true, false, true," if train else "siren_forward_kernel<true, false, false,")
     else:
         traffic = pmc_traffic("nerf_forward_kernel<false, false, true>" if train else "nerf_forward_kernel<false, false, false>")
     flops_per_launch = B * 128 * (FLOP_SIREN if siren else FLOP_FULL)
@@ -444,12 +444,12 @@ def main():
                 "roofline": {"bound": "mfma", "kernel": "siren_forward_kernel<true,false,false> (fine pass, 128 samples/ray, "
                              "inference)", "achieved": fl / (k_i * 1e-3) / 1e12, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                              "frac": fl / (k_i * 1e-3) / 1e12 / PEAK_F32_MFMA, "flops_per_launch": fl, "avg_launch_ms": k_i,
-                             "traffic": pmc_traffic("siren_forward_kernel<true, false, false>")},
+                             "traffic": pmc_traffic("siren_forward_kernel<true, false, false,")},
                 "roofline_train_forward": {"bound": "mfma", "kernel": "siren_forward_kernel<true,false,true> (fine pass, saves "
                                            "activations)", "achieved": fl / (k_t * 1e-3) / 1e12, "peak": PEAK_F32_MFMA,
                                            "unit": "TFLOP/s", "frac": fl / (k_t * 1e-3) / 1e12 / PEAK_F32_MFMA,
                                            "avg_launch_ms": k_t,
-                                           "traffic": pmc_traffic("siren_forward_kernel<true, false, true>")}}
+                                           "traffic": pmc_traffic("siren_forward_kernel<true, false, true,")}}
             del sm
         ops.set_profile_hook(None)
         extra["eg3d"] = eg3d_bench(dev, ks, kw)

@@ -11,6 +11,8 @@
 //     a tile-major image.
 //  2. dW_l = dZ_l^T . X_l: the NeRF dW GEMM (dw_core.h) on a 12-task plan of exactly 256 workgroups.
 //  3. deterministic slab reduction (dw_core.h): bit-reproducible gradients.
+#include <stdlib.h>
+
 #include "dw_core.h"
 #include "siren_core.h"
 
@@ -50,7 +52,9 @@ __device__ __forceinline__ f32x4 film_grad(f32x4 dh, const f32x16 &s, const unsi
     for (int t = 0; t < 4; ++t) {
         const float sv = s[4 * q + t];
         const float c2 = (1.0f - sv) * (1.0f + sv);
-        const float ca = __builtin_sqrtf(fmaxf(c2, 0.f));
+        // the raw v_sqrt_f32 (1 ulp): sqrtf() is expanded to the correctly rounded sequence (scale, refine, classify:
+        // ~14 instructions) which tripled this epilogue's vector work -- and |cos| feeds a product, not a parity check
+        const float ca = __builtin_amdgcn_sqrtf(fmaxf(c2, 0.f));
         // the cosine's sign: bit (sh + t) of the mask word moved to bit 31 and OR-ed in (v_lshlrev + v_and_or)
         const unsigned sgn = (mk[jb >> 1] << (31 - (16 * (jb & 1) + 4 * q + t))) & 0x80000000u;
         dh[t] = dh[t] * (fr[t] * __uint_as_float(__float_as_uint(ca) | sgn));
@@ -161,10 +165,17 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
 // ---------------------------------------------------------------------------
 // 2. dW: same GEMM as the NeRF backward on the SIREN images
 // ---------------------------------------------------------------------------
+#ifdef NERFMI_TIMING
+__device__ unsigned long long nerfmi_dbg_siren_dw[512];   // per-workgroup shader-clock duration (experiment builds)
+#endif
+
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 siren_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__restrict__ saved, int64_t ld,
                 float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef NERFMI_TIMING
+    const unsigned long long t_start = __builtin_readcyclecounter();
+#endif
     int ti = 0;
     for (int i = 1; i < plan.n_tasks; ++i)
         if ((int)blockIdx.x >= plan.t[i].wg0) ti = i;
@@ -175,6 +186,9 @@ siren_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__rest
         case 1: dw_task<2, 2, 4, 1, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 64
         default: dw_task<1, 2, 1, 4, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;  // 32 x 256
     }
+#ifdef NERFMI_TIMING
+    if (threadIdx.x == 0) nerfmi_dbg_siren_dw[blockIdx.x] = __builtin_readcyclecounter() - t_start;
+#endif
 }
 
 static const int SKIND_JB[3] = {8, 8, 1};
@@ -197,7 +211,12 @@ static DwPlan siren_plan(int64_t ld) {
     add(2, SW_DSIG, 1, SS_H + 256 * 7, 256, 16, 0, 256, 17);                                    // final_layer
     P.n_tasks = n;
     // 8 x 28 + 2 x 10 + 2 x 6 = 256 workgroups, one per CU (see mlp_bwd.hip make_plan for how the shares were chosen)
-    static const int chunks[3] = {28, 10, 6};
+    static const int chunks_default[3] = {28, 10, 6};
+    const int *chunks = chunks_default;
+    int chunks_env[3];
+    if (const char *e = getenv("NERFMI_SIREN_DW_CHUNKS")) {     // experiments (tools/exp_siren_dw_timing.py): "c0,c1,c2"
+        if (sscanf(e, "%d,%d,%d", chunks_env, chunks_env + 1, chunks_env + 2) == 3) chunks = chunks_env;
+    }
     dw_finish_plan(P, SKIND_JB, SKIND_KB, chunks, ld);
     return P;
 }
@@ -207,6 +226,12 @@ static DwPlan siren_plan(int64_t ld) {
 using namespace nerfmi;
 
 extern "C" {
+
+#ifdef NERFMI_TIMING
+int nerfmi_debug_timing_siren_dw(unsigned long long *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(nerfmi_dbg_siren_dw), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // + one dump tile for waves past the end (mlp_core.h RowImage)
 size_t nerfmi_siren_saved_floats(int64_t n_points) {
