@@ -147,7 +147,11 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
     auto no_pre = [](int) { return 0; };
     __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
     const int wid = threadIdx.x >> 6;
-    const float *bias = packed + SOFF_BIAS + 4 * half;
+    // the nine layers' biases staged in LDS: an L2-latency bias load sits right in front of each block's first MFMA
+    // (measured here: training step 5.77 -> 5.71 ms; the same change made the NeRF kernels 1 % SLOWER and is not in mlp.hip)
+    __shared__ __attribute__((aligned(16))) float lbias[9 * 256];
+    for (int i = threadIdx.x; i < 9 * 256; i += blockDim.x) lbias[i] = packed[SOFF_BIAS + i];
+    const float *bias = lbias + 4 * half;
     f32x16 hA[8], hB[8];                   // alternate: a layer reads one, its epilogue writes the other (no copies)
     WeightStage ws;
     // ring phases: network.0 is 2 stages, every hidden layer 16, so the hidden and color layers start at phase 2
