@@ -88,7 +88,6 @@ __device__ __forceinline__ void bilinear_plane(const float *__restrict__ plane, 
     }
 }
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 // MODE 0: features out (N,3,P,C)   [sample_from_planes, renderer.py:55-65]
 // MODE 1: fused decoder -> rgb (N,P,3), sigma (N,P)   [run_model, renderer.py:144-151 + triplane.py:155-167]
@@ -132,14 +131,14 @@ triplane_kernel(const float *__restrict__ planes, int N, int H, int W, const flo
         }
         if (MODE == 1) {
 #pragma unroll
-            for (int k = 0; k < EC; ++k) m[k] = __fdiv_rn(m[k], 3.f);             // sampled_features.mean(1), triplane.py:157
+            for (int k = 0; k < EC; ++k) m[k] = div3_rn(m[k]);                    // sampled_features.mean(1), triplane.py:157
             const float *w0 = dec, *b0 = dec + DEC_H * EC, *w1 = b0 + DEC_H, *b1 = w1 + 4 * DEC_H;
             float o4[4] = {b1[0], b1[1], b1[2], b1[3]};
             for (int j = 0; j < DEC_H; ++j) {                                     // uniform addresses -> scalar loads
                 float h = b0[j];
 #pragma unroll
                 for (int k = 0; k < EC; ++k) h = __builtin_fmaf(w0[j * EC + k], m[k], h);
-                h = softplus_f(h);
+                h = softplus_hw(h);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o4[k] = __builtin_fmaf(w1[k * DEC_H + j], h, o4[k]);
             }

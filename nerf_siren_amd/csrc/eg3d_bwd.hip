@@ -22,7 +22,6 @@ constexpr int DEC_FLOATS = DEC_H * EC + DEC_H + 4 * DEC_H + 4;
 constexpr int AUX_F = DEC_H + EC + DEC_H + 4;     // [d_pre(64) | m(32) | h(64) | d_x(4)] per point
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __fdiv_rn(1.f, __fadd_rn(1.f, expf(-x))); }
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 // ---------------------------------------------------------------------------
 // MipRayMarcher2 backward
@@ -212,7 +211,7 @@ triplane_backward_kernel(const float *__restrict__ planes, int N, int H, int W, 
             for (int k = 0; k < EC; ++k) m[k] = (pl == 0) ? f[k] : __fadd_rn(m[k], f[k]);
         }
 #pragma unroll
-        for (int k = 0; k < EC; ++k) m[k] = __fdiv_rn(m[k], 3.f);
+        for (int k = 0; k < EC; ++k) m[k] = div3_rn(m[k]);
         const float *w0 = dec, *b0 = dec + DEC_H * EC, *w1 = b0 + DEC_H, *b1 = w1 + 4 * DEC_H;
         // pass 1: outputs
         float o4[4] = {b1[0], b1[1], b1[2], b1[3]};
@@ -220,7 +219,7 @@ triplane_backward_kernel(const float *__restrict__ planes, int N, int H, int W, 
             float h = b0[j];
 #pragma unroll
             for (int k = 0; k < EC; ++k) h = __builtin_fmaf(w0[j * EC + k], m[k], h);
-            h = softplus_f(h);
+            h = softplus_hw(h);
 #pragma unroll
             for (int k = 0; k < 4; ++k) o4[k] = __builtin_fmaf(w1[k * DEC_H + j], h, o4[k]);
         }
@@ -239,11 +238,11 @@ triplane_backward_kernel(const float *__restrict__ planes, int N, int H, int W, 
             float pre = b0[j];
 #pragma unroll
             for (int k = 0; k < EC; ++k) pre = __builtin_fmaf(w0[j * EC + k], m[k], pre);
-            const float h = softplus_f(pre);
+            const float h = softplus_hw(pre);
             float dh = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) dh = __builtin_fmaf(w1[k * DEC_H + j], dx[k], dh);
-            const float dpre = dh * (pre > 20.f ? 1.f : sigmoidf_(pre));
+            const float dpre = dh * (pre > 20.f ? 1.f : sigmoid_hw(pre));
             if (ok) {
                 aux[(int64_t)j * aux_ld + idx] = dpre;
                 aux[(int64_t)(DEC_H + EC + j) * aux_ld + idx] = h;
