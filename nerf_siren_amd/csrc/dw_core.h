@@ -73,7 +73,12 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
     auto load_slot = [&](int i, int64_t t) {
         const float *src = (i < JB) ? abase + t * (int64_t)(AROWS * 32) + i * 1024
                                     : bbase + t * (int64_t)(BROWS * 32) + (i - JB) * 1024;     // wave-uniform
+#ifdef NERFMI_EXP_DW_TLOAD
         stage[i] = ldg4(src + voff);
+#else
+        // streamed exactly once by exactly one workgroup: non-temporal, so the 2.7 GB of dZ / X tiles do not sweep L2
+        stage[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + voff));
+#endif
     };
     auto write_slot = [&](int i, float *buf) {
         *reinterpret_cast<f32x4 *>(buf + i * (32 * LROW) + loff) = stage[i];

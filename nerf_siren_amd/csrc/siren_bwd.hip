@@ -31,7 +31,7 @@ __device__ __forceinline__ f32x16 load_block(const RowImage &im, int row0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[4 * q + t] = src[(8 * q + t) * 32];
+        for (int t = 0; t < 4; ++t) v[4 * q + t] = __builtin_nontemporal_load(src + (8 * q + t) * 32);   // read once: keep L2 for the weights
     return v;
 }
 
