@@ -45,8 +45,25 @@ const char *nerfmi_last_error(void);
 int nerfmi_sample_stratified(const float *rays, const float *perturb_rand, int n_rays, int n_samples,
                              int use_disp, float perturb, float *z_out, nerfmi_stream_t stream);
 
-/* The random draws of one render_rays call from ONE launch (perf mode; parity tests inject the reference's captured
- * draws instead): perturb_rand (n_perturb floats, U[0,1)) [rendering.py:221], noise_coarse (N(0,1)) [:170], u (U[0,1))
+/* Perf-mode variants that draw IN the kernel from Philox4x32-10 streams addressed by (seed, offset, segment) instead of
+ * reading a tensor of draws (segments: 0 perturb_rand, 1 noise_coarse, 2 u, 3 noise_fine).  Element e of a segment is
+ * bit-identical to what nerfmi_render_draws(seed, offset, ...) writes at index e, so the fused and the materialised paths
+ * render the same image; the compositor's backward regenerates its forward's noise from the same key. */
+int nerfmi_sample_stratified_philox(const float *rays, uint64_t seed, uint64_t offset, int n_rays, int n_samples,
+                                    int use_disp, float perturb, float *z_out, nerfmi_stream_t stream);
+int nerfmi_composite_philox(const float *field, int sigma_only, const float *z, const float *rays, uint64_t seed,
+                            uint64_t offset, int segment, float noise_std, int n_rays, int n_per_ray, int white_back,
+                            float *weights_out, float *rgb_out, float *depth_out, float *opacity_out,
+                            nerfmi_stream_t stream);
+int nerfmi_composite_backward_philox(const float *field, const float *z, const float *rays, uint64_t seed, uint64_t offset,
+                                     int segment, float noise_std, int n_rays, int n_per_ray, int white_back,
+                                     const float *g_rgb, const float *g_depth, const float *g_opacity, float *grad_field,
+                                     nerfmi_stream_t stream);
+int nerfmi_importance_resample_philox(const float *z_coarse, const float *weights_coarse, uint64_t seed, uint64_t offset,
+                                      int n_rays, int n_samples, int n_importance, float *z_new_out, float *z_fine_out,
+                                      nerfmi_stream_t stream);
+
+/* The same streams written to memory by ONE launch (tests; callers that want the tensors): perturb_rand (n_perturb floats, U[0,1)) [rendering.py:221], noise_coarse (N(0,1)) [:170], u (U[0,1))
  * [:47], noise_fine (N(0,1)).  Philox4x32-10 keyed by `seed`, counter = (quad, segment, offset): the same
  * (seed, offset) always gives the same draws, independent of the sizes of the other segments.  A segment with size 0
  * is skipped (its pointer may be NULL). */

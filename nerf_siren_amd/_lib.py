@@ -20,6 +20,10 @@ SIGNATURES = {
     "nerfmi_version": (C.c_int, []),
     "nerfmi_last_error": (C.c_char_p, []),
     "nerfmi_sample_stratified": (_i, [_f, _f, _i, _i, _i, _fl, _f, _f]),
+    "nerfmi_sample_stratified_philox": (_i, [_f, C.c_uint64, C.c_uint64, _i, _i, _i, _fl, _f, _f]),
+    "nerfmi_composite_philox": (_i, [_f, _i, _f, _f, C.c_uint64, C.c_uint64, _i, _fl, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "nerfmi_composite_backward_philox": (_i, [_f, _f, _f, C.c_uint64, C.c_uint64, _i, _fl, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "nerfmi_importance_resample_philox": (_i, [_f, _f, C.c_uint64, C.c_uint64, _i, _i, _i, _f, _f, _f]),
     "nerfmi_render_draws": (_i, [C.c_uint64, C.c_uint64, _i64, _f, _i64, _f, _i64, _f, _i64, _f, _f]),
     "nerfmi_embed": (_i, [_f, _i64, _i, _f, _f]),
     "nerfmi_nerf_packed_floats": (C.c_size_t, []),

@@ -229,7 +229,11 @@ struct RowImage {
     // epilogue's vector work between them instead of letting it issue in the MFMAs' shadow.
     __device__ __forceinline__ void init(float *base, int64_t tile_idx, int64_t n_tiles, int rows, int lane_, bool ok_,
                                          bool live_) {
+#ifdef NERFMI_EXP_DUMMYSTORE
+        tile = base + (live_ ? tile_idx % NERFMI_EXP_DUMMYSTORE : n_tiles) * (int64_t)(rows * 32);   // experiment: stores that stay in cache
+#else
         tile = base + (live_ ? tile_idx : n_tiles) * (int64_t)(rows * 32);
+#endif
         lane = lane_;
         ok = ok_;
         live = live_;

@@ -11,6 +11,64 @@
 
 namespace nerfmi {
 
+// ---------------------------------------------------------------------------
+// The four random draws of one render_rays call (SURVEY 3.2: rand(N,S) [rendering.py:221], randn(N,S) [:170],
+// rand(N,F) [:47], randn(N,S+F)) from a counter-based generator instead of four aten distribution launches:
+// Philox4x32-10 (Salmon et al., SC'11; Random123 known-answer vectors in tests/), key = seed, counter =
+// (quad index, segment, offset lo, offset hi); one 128-bit block = four floats of one segment.
+// uniform: (x >> 8) * 2^-24 in [0,1) (24 bits, like torch.rand); normal: Box-Muller on two such pairs.
+// Perf mode draws IN the consuming kernels (the *_philox entry points: no draw ever touches memory; the compositor's
+// backward regenerates its forward's noise from the same key); nerfmi_render_draws materialises the same streams.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// (seed, offset, segment) address one stream of draws; `on` = 0 means "no generator" (draws injected or not needed).
+// Segments: 0 perturb_rand, 1 noise_coarse, 2 u, 3 noise_fine.  The SAME functions serve nerfmi_render_draws (draws
+// written to memory) and the kernels that draw in place (sample_stratified / composite / composite_backward /
+// importance_resample with a key): element e of a segment is the same float either way, bit for bit.
+struct DrawKey {
+    unsigned long long seed, offset;
+    int seg, on;
+};
+
+// the four floats of quad `i` of the key's segment (uniform for segments 0, 2; Box-Muller normals for 1, 3)
+__device__ __forceinline__ void draw_quad(const DrawKey &k, long long i, float (&v)[4]) {
+    unsigned c[4] = {(unsigned)i, (unsigned)k.seg | ((unsigned)(i >> 32) << 2), (unsigned)k.offset, (unsigned)(k.offset >> 32)};
+    philox4x32_10(c, (unsigned)k.seed, (unsigned)(k.seed >> 32));
+    if (k.seg & 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = (float)((c[2 * h] >> 8) + 1u) * 5.9604644775390625e-8f;      // (0, 1]
+            const float u2 = (float)(c[2 * h + 1] >> 8) * 5.9604644775390625e-8f;         // [0, 1)
+            const float r = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            v[2 * h] = r * cs;
+            v[2 * h + 1] = r * sn;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = (float)(c[t] >> 8) * 5.9604644775390625e-8f;
+    }
+}
+__device__ __forceinline__ float draw_one(const DrawKey &k, long long e) {
+    float v[4];
+    draw_quad(k, e >> 2, v);
+    const int t = (int)(e & 3);
+    return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3]));
+}
+
+
 static thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -31,7 +89,7 @@ __device__ __forceinline__ float z_at(int i, int S, float near, float far, bool 
     return __fdiv_rn(1.0f, __fadd_rn(a, b));
 }
 
-__global__ void sample_stratified_kernel(const float *__restrict__ rays, const float *__restrict__ prand,
+__global__ void sample_stratified_kernel(const float *__restrict__ rays, const float *__restrict__ prand, DrawKey key,
                                          int n_rays, int S, int use_disp, float perturb,
                                          float *__restrict__ z_out) {
     const int64_t total = (int64_t)n_rays * S;
@@ -45,7 +103,7 @@ __global__ void sample_stratified_kernel(const float *__restrict__ rays, const f
             float lower = z, upper = z;
             if (i > 0) lower = __fmul_rn(0.5f, __fadd_rn(z_at(i - 1, S, near, far, use_disp), z));
             if (i < S - 1) upper = __fmul_rn(0.5f, __fadd_rn(z, z_at(i + 1, S, near, far, use_disp)));
-            const float pr = __fmul_rn(perturb, prand[idx]);
+            const float pr = __fmul_rn(perturb, prand ? prand[idx] : draw_one(key, idx));      // :221 torch.rand
             z = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), pr));
         }
         z_out[idx] = z;
@@ -53,26 +111,8 @@ __global__ void sample_stratified_kernel(const float *__restrict__ rays, const f
 }
 
 // ---------------------------------------------------------------------------
-// The four random draws of one render_rays call (SURVEY 3.2: rand(N,S) [rendering.py:221], randn(N,S) [:170],
-// rand(N,F) [:47], randn(N,S+F)) from ONE launch of a counter-based generator, instead of four aten distribution
-// launches: Philox4x32-10 (Salmon et al., SC'11; Random123 known-answer vectors in tests/), key = seed, counter =
-// (quad index, segment, offset lo, offset hi); each thread turns one 128-bit block into four floats of one segment.
-// uniform: (x >> 8) * 2^-24 in [0,1) (24 bits, like torch.rand); normal: Box-Muller on two such pairs.  The draws
-// are written to memory rather than regenerated inside the consuming kernels: the compositor's backward needs the
-// SAME noise as its forward, and 5 B/sample of traffic is cheaper than two more Philox + Box-Muller evaluations.
+// nerfmi_render_draws: the draws written to memory (one launch for all four segments)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-
 struct DrawSegs {
     float *out[4];
     long long n[4];          // floats in the segment (0 = skipped); segments 0, 2 uniform, 1, 3 normal
@@ -87,24 +127,9 @@ __global__ void render_draws_kernel(DrawSegs G, unsigned long long seed, unsigne
         for (int k = 1; k < 4; ++k)
             if (qd >= G.quad0[k]) seg = k;
         const long long i = qd - G.quad0[seg];
-        unsigned c[4] = {(unsigned)i, (unsigned)seg | ((unsigned)(i >> 32) << 2), (unsigned)offset, (unsigned)(offset >> 32)};
-        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+        const DrawKey key = {seed, offset, seg, 1};
         float v[4];
-        if (seg & 1) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float u1 = (float)((c[2 * h] >> 8) + 1u) * 5.9604644775390625e-8f;      // (0, 1]
-                const float u2 = (float)(c[2 * h + 1] >> 8) * 5.9604644775390625e-8f;         // [0, 1)
-                const float r = sqrtf(-2.0f * logf(u1));
-                float sn, cs;
-                sincosf(6.283185307179586f * u2, &sn, &cs);
-                v[2 * h] = r * cs;
-                v[2 * h + 1] = r * sn;
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = (float)(c[t] >> 8) * 5.9604644775390625e-8f;
-        }
+        draw_quad(key, i, v);
         float *dst = G.out[seg] + 4 * i;
         const long long left = G.n[seg] - 4 * i;
 #pragma unroll
@@ -149,8 +174,8 @@ template <int SPL, bool SIGMA_ONLY>
 __device__ __forceinline__ void composite_forward_ray(RaySamples<SPL> &R, const float *__restrict__ field,
                                                       const float *__restrict__ zrow,
                                                       const float *__restrict__ ray,
-                                                      const float *__restrict__ noise_row, float noise_std,
-                                                      int P, int lane) {
+                                                      const float *__restrict__ noise_row, const DrawKey &key,
+                                                      int64_t base, float noise_std, int P, int lane) {
     const float dn = ray_norm(ray[3], ray[4], ray[5]);
     double lp = 1.0;  // local running product
     double pl[SPL];
@@ -173,6 +198,7 @@ __device__ __forceinline__ void composite_forward_ray(RaySamples<SPL> &R, const 
         delta = __fmul_rn(delta, dn);                                        // :168
         float sg = sigma;
         if (noise_row) sg = __fadd_rn(sigma, __fmul_rn(noise_row[sc], noise_std));   // :170,173
+        else if (key.on) sg = __fadd_rn(sigma, __fmul_rn(draw_one(key, base + sc), noise_std));   // torch.randn in place
         // exp evaluated in fp64 and rounded once: the correctly rounded fp32 value, which is what
         // the oracle specifies (torch's SLEEF expf is within 1 ulp of it)
         const float e = (float)exp((double)(-__fmul_rn(delta, fmaxf(sg, 0.f))));
@@ -196,7 +222,7 @@ __device__ __forceinline__ void composite_forward_ray(RaySamples<SPL> &R, const 
 template <int SPL, bool SIGMA_ONLY>
 __global__ void __launch_bounds__(64)
 composite_kernel(const float *__restrict__ field, const float *__restrict__ z, const float *__restrict__ rays,
-                 const float *__restrict__ noise, float noise_std, int n_rays, int P, int white_back,
+                 const float *__restrict__ noise, DrawKey key, float noise_std, int n_rays, int P, int white_back,
                  float *__restrict__ weights_out, float *__restrict__ rgb_out, float *__restrict__ depth_out,
                  float *__restrict__ opacity_out) {
     const int lane = threadIdx.x;
@@ -204,7 +230,7 @@ composite_kernel(const float *__restrict__ field, const float *__restrict__ z, c
         RaySamples<SPL> R;
         const int64_t base = (int64_t)r * P;
         composite_forward_ray<SPL, SIGMA_ONLY>(R, field + base * (SIGMA_ONLY ? 1 : 4), z + base, rays + (int64_t)r * 8,
-                                               noise ? noise + base : nullptr, noise_std, P, lane);
+                                               noise ? noise + base : nullptr, key, base, noise_std, P, lane);
         double so = 0, sr = 0, sgc = 0, sb = 0, sd = 0;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
@@ -243,7 +269,7 @@ composite_kernel(const float *__restrict__ field, const float *__restrict__ z, c
 template <int SPL>
 __global__ void __launch_bounds__(64)
 composite_backward_kernel(const float *__restrict__ field, const float *__restrict__ z,
-                          const float *__restrict__ rays, const float *__restrict__ noise, float noise_std,
+                          const float *__restrict__ rays, const float *__restrict__ noise, DrawKey key, float noise_std,
                           int n_rays, int P, int white_back, const float *__restrict__ g_rgb,
                           const float *__restrict__ g_depth, const float *__restrict__ g_opacity,
                           float *__restrict__ grad_field) {
@@ -252,7 +278,7 @@ composite_backward_kernel(const float *__restrict__ field, const float *__restri
         RaySamples<SPL> R;
         const int64_t base = (int64_t)r * P;
         composite_forward_ray<SPL, false>(R, field + base * 4, z + base, rays + (int64_t)r * 8,
-                                          noise ? noise + base : nullptr, noise_std, P, lane);
+                                          noise ? noise + base : nullptr, key, base, noise_std, P, lane);
         const double gr = g_rgb ? (double)g_rgb[r * 3 + 0] : 0.0, gg = g_rgb ? (double)g_rgb[r * 3 + 1] : 0.0,
                      gb = g_rgb ? (double)g_rgb[r * 3 + 2] : 0.0;
         const double gd = g_depth ? (double)g_depth[r] : 0.0, go = g_opacity ? (double)g_opacity[r] : 0.0;
@@ -400,7 +426,7 @@ merge_sorted_kernel(const float *__restrict__ za, const float *__restrict__ zb, 
 // rendering.py:242-247 fused: z_mid -> sample_pdf(z_mid, w[:,1:-1]) -> sort(cat[z, z_new])
 __global__ void __launch_bounds__(64)
 importance_resample_kernel(const float *__restrict__ zc, const float *__restrict__ wc, const float *__restrict__ u_g,
-                           int n_rays, int S, int F, int npad, float *__restrict__ z_new_out,
+                           DrawKey key, int n_rays, int S, int F, int npad, float *__restrict__ z_new_out,
                            float *__restrict__ z_fine_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nw = S - 2, nb = S - 1, n = S + F;
@@ -414,7 +440,7 @@ importance_resample_kernel(const float *__restrict__ zc, const float *__restrict
         for (int k = S + F + lane; k < npad; k += WAVE) srt[k] = INFINITY;
         build_cdf_lds(cdf, wc + (int64_t)r * S + 1, nw, 1, lane);
         for (int f = lane; f < F; f += WAVE) {
-            const float u = u_g ? u_g[(int64_t)r * F + f] : linspace01(f, F);
+            const float u = u_g ? u_g[(int64_t)r * F + f] : (key.on ? draw_one(key, (int64_t)r * F + f) : linspace01(f, F));
             int inds;
             const float s = search_lerp_one(cdf, bins, nw, u, inds);
             srt[S + f] = s;
@@ -502,16 +528,28 @@ extern "C" {
 int nerfmi_version(void) { return 100; }
 const char *nerfmi_last_error(void) { return g_err; }
 
-int nerfmi_sample_stratified(const float *rays, const float *perturb_rand, int n_rays, int n_samples, int use_disp,
-                             float perturb, float *z_out, nerfmi_stream_t stream) {
-    NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 1, "sample_stratified: bad sizes n_rays=%d n_samples=%d", n_rays, n_samples);
+static int sample_stratified_impl(const char *who, const float *rays, const float *perturb_rand, DrawKey key, int n_rays,
+                                  int n_samples, int use_disp, float perturb, float *z_out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 1, "%s: bad sizes n_rays=%d n_samples=%d", who, n_rays, n_samples);
     if (n_rays == 0) return NERFMI_OK;
-    NERFMI_REQUIRE(rays && z_out, "sample_stratified: null pointer");
-    NERFMI_REQUIRE(!(perturb > 0.f) || perturb_rand, "sample_stratified: perturb>0 needs perturb_rand");
+    NERFMI_REQUIRE(rays && z_out, "%s: null pointer", who);
+    NERFMI_REQUIRE(!(perturb > 0.f) || perturb_rand || key.on, "%s: perturb>0 needs perturb_rand", who);
     const int64_t total = (int64_t)n_rays * n_samples;
     hipLaunchKernelGGL(sample_stratified_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, rays,
-                       perturb_rand, n_rays, n_samples, use_disp, perturb, z_out);
-    return check_launch("sample_stratified");
+                       perturb_rand, key, n_rays, n_samples, use_disp, perturb, z_out);
+    return check_launch(who);
+}
+
+int nerfmi_sample_stratified(const float *rays, const float *perturb_rand, int n_rays, int n_samples, int use_disp,
+                             float perturb, float *z_out, nerfmi_stream_t stream) {
+    return sample_stratified_impl("sample_stratified", rays, perturb_rand, DrawKey{0, 0, 0, 0}, n_rays, n_samples, use_disp,
+                                  perturb, z_out, stream);
+}
+
+int nerfmi_sample_stratified_philox(const float *rays, uint64_t seed, uint64_t offset, int n_rays, int n_samples,
+                                    int use_disp, float perturb, float *z_out, nerfmi_stream_t stream) {
+    return sample_stratified_impl("sample_stratified_philox", rays, nullptr, DrawKey{seed, offset, 0, 1}, n_rays, n_samples,
+                                  use_disp, perturb, z_out, stream);
 }
 
 int nerfmi_render_draws(uint64_t seed, uint64_t offset, int64_t n_perturb, float *perturb_rand, int64_t n_noise_coarse,
@@ -555,43 +593,76 @@ int nerfmi_embed(const float *x, int64_t n, int n_freqs, float *out, nerfmi_stre
         else { CALL(16); }                                              \
     } while (0)
 
-int nerfmi_composite(const float *field, int sigma_only, const float *z, const float *rays, const float *noise,
-                     float noise_std, int n_rays, int n_per_ray, int white_back, float *weights_out, float *rgb_out,
-                     float *depth_out, float *opacity_out, nerfmi_stream_t stream) {
-    NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && n_per_ray <= 1024, "composite: n_per_ray=%d out of [1,1024]", n_per_ray);
+static int composite_impl(const char *who, const float *field, int sigma_only, const float *z, const float *rays,
+                          const float *noise, DrawKey key, float noise_std, int n_rays, int n_per_ray, int white_back,
+                          float *weights_out, float *rgb_out, float *depth_out, float *opacity_out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && n_per_ray <= 1024, "%s: n_per_ray=%d out of [1,1024]", who, n_per_ray);
     if (n_rays == 0) return NERFMI_OK;
-    NERFMI_REQUIRE(field && z && rays, "composite: null input");
+    NERFMI_REQUIRE(field && z && rays, "%s: null input", who);
     const dim3 grid(n_rays < 65536 ? n_rays : 65536), block(64);
     hipStream_t st = (hipStream_t)stream;
-    if (noise_std == 0.f) noise = nullptr;
+    if (noise_std == 0.f) { noise = nullptr; key.on = 0; }
 #define CALL(SPL)                                                                                                   \
     if (sigma_only)                                                                                                 \
-        hipLaunchKernelGGL((composite_kernel<SPL, true>), grid, block, 0, st, field, z, rays, noise, noise_std,     \
+        hipLaunchKernelGGL((composite_kernel<SPL, true>), grid, block, 0, st, field, z, rays, noise, key, noise_std, \
                            n_rays, n_per_ray, white_back, weights_out, rgb_out, depth_out, opacity_out);            \
     else                                                                                                            \
-        hipLaunchKernelGGL((composite_kernel<SPL, false>), grid, block, 0, st, field, z, rays, noise, noise_std,    \
+        hipLaunchKernelGGL((composite_kernel<SPL, false>), grid, block, 0, st, field, z, rays, noise, key, noise_std, \
                            n_rays, n_per_ray, white_back, weights_out, rgb_out, depth_out, opacity_out)
     NERFMI_SPL_DISPATCH(n_per_ray, CALL);
 #undef CALL
-    return check_launch("composite");
+    return check_launch(who);
+}
+
+int nerfmi_composite(const float *field, int sigma_only, const float *z, const float *rays, const float *noise,
+                     float noise_std, int n_rays, int n_per_ray, int white_back, float *weights_out, float *rgb_out,
+                     float *depth_out, float *opacity_out, nerfmi_stream_t stream) {
+    return composite_impl("composite", field, sigma_only, z, rays, noise, DrawKey{0, 0, 0, 0}, noise_std, n_rays, n_per_ray,
+                          white_back, weights_out, rgb_out, depth_out, opacity_out, stream);
+}
+
+int nerfmi_composite_philox(const float *field, int sigma_only, const float *z, const float *rays, uint64_t seed,
+                            uint64_t offset, int segment, float noise_std, int n_rays, int n_per_ray, int white_back,
+                            float *weights_out, float *rgb_out, float *depth_out, float *opacity_out,
+                            nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(segment == 1 || segment == 3, "composite_philox: segment must be 1 (coarse) or 3 (fine)");
+    return composite_impl("composite_philox", field, sigma_only, z, rays, nullptr, DrawKey{seed, offset, segment, 1},
+                          noise_std, n_rays, n_per_ray, white_back, weights_out, rgb_out, depth_out, opacity_out, stream);
+}
+
+static int composite_backward_impl(const char *who, const float *field, const float *z, const float *rays,
+                                   const float *noise, DrawKey key, float noise_std, int n_rays, int n_per_ray,
+                                   int white_back, const float *g_rgb, const float *g_depth, const float *g_opacity,
+                                   float *grad_field, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && n_per_ray <= 1024, "%s: n_per_ray=%d out of [1,1024]", who, n_per_ray);
+    if (n_rays == 0) return NERFMI_OK;
+    NERFMI_REQUIRE(field && z && rays && grad_field, "%s: null pointer", who);
+    const dim3 grid(n_rays < 65536 ? n_rays : 65536), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    if (noise_std == 0.f) { noise = nullptr; key.on = 0; }
+#define CALL(SPL)                                                                                                 \
+    hipLaunchKernelGGL((composite_backward_kernel<SPL>), grid, block, 0, st, field, z, rays, noise, key, noise_std, \
+                       n_rays, n_per_ray, white_back, g_rgb, g_depth, g_opacity, grad_field)
+    NERFMI_SPL_DISPATCH(n_per_ray, CALL);
+#undef CALL
+    return check_launch(who);
 }
 
 int nerfmi_composite_backward(const float *field, const float *z, const float *rays, const float *noise,
                               float noise_std, int n_rays, int n_per_ray, int white_back, const float *g_rgb,
                               const float *g_depth, const float *g_opacity, float *grad_field,
                               nerfmi_stream_t stream) {
-    NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && n_per_ray <= 1024, "composite_backward: n_per_ray=%d out of [1,1024]", n_per_ray);
-    if (n_rays == 0) return NERFMI_OK;
-    NERFMI_REQUIRE(field && z && rays && grad_field, "composite_backward: null pointer");
-    const dim3 grid(n_rays < 65536 ? n_rays : 65536), block(64);
-    hipStream_t st = (hipStream_t)stream;
-    if (noise_std == 0.f) noise = nullptr;
-#define CALL(SPL)                                                                                                 \
-    hipLaunchKernelGGL((composite_backward_kernel<SPL>), grid, block, 0, st, field, z, rays, noise, noise_std,    \
-                       n_rays, n_per_ray, white_back, g_rgb, g_depth, g_opacity, grad_field)
-    NERFMI_SPL_DISPATCH(n_per_ray, CALL);
-#undef CALL
-    return check_launch("composite_backward");
+    return composite_backward_impl("composite_backward", field, z, rays, noise, DrawKey{0, 0, 0, 0}, noise_std, n_rays,
+                                   n_per_ray, white_back, g_rgb, g_depth, g_opacity, grad_field, stream);
+}
+
+int nerfmi_composite_backward_philox(const float *field, const float *z, const float *rays, uint64_t seed, uint64_t offset,
+                                     int segment, float noise_std, int n_rays, int n_per_ray, int white_back,
+                                     const float *g_rgb, const float *g_depth, const float *g_opacity, float *grad_field,
+                                     nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(segment == 1 || segment == 3, "composite_backward_philox: segment must be 1 (coarse) or 3 (fine)");
+    return composite_backward_impl("composite_backward_philox", field, z, rays, nullptr, DrawKey{seed, offset, segment, 1},
+                                   noise_std, n_rays, n_per_ray, white_back, g_rgb, g_depth, g_opacity, grad_field, stream);
 }
 
 static int sample_pdf_common(const float *bins, const float *weights, const float *cdf_in, const float *u, int n_rays,
@@ -644,19 +715,33 @@ int nerfmi_merge_sorted(const float *za, const float *zb, int n_rays, int na, in
     return check_launch("merge_sorted");
 }
 
-int nerfmi_importance_resample(const float *z_coarse, const float *weights_coarse, const float *u, int n_rays,
-                               int n_samples, int n_importance, float *z_new_out, float *z_fine_out,
-                               nerfmi_stream_t stream) {
+static int importance_resample_impl(const char *who, const float *z_coarse, const float *weights_coarse, const float *u,
+                                    DrawKey key, int n_rays, int n_samples, int n_importance, float *z_new_out,
+                                    float *z_fine_out, nerfmi_stream_t stream) {
     NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 3 && n_importance >= 1 && n_samples + n_importance <= 8192,
-                   "importance_resample: bad sizes S=%d F=%d (need S>=3, F>=1, S+F<=8192)", n_samples, n_importance);
+                   "%s: bad sizes S=%d F=%d (need S>=3, F>=1, S+F<=8192)", who, n_samples, n_importance);
     if (n_rays == 0) return NERFMI_OK;
-    NERFMI_REQUIRE(z_coarse && weights_coarse && z_fine_out, "importance_resample: null pointer");
+    NERFMI_REQUIRE(z_coarse && weights_coarse && z_fine_out, "%s: null pointer", who);
     const int npad = next_pow2(n_samples + n_importance);
     const size_t lds = sizeof(float) * (2 * (n_samples - 1) + npad);
     hipLaunchKernelGGL(importance_resample_kernel, dim3(n_rays < 65536 ? n_rays : 65536), dim3(64), lds,
-                       (hipStream_t)stream, z_coarse, weights_coarse, u, n_rays, n_samples, n_importance, npad,
+                       (hipStream_t)stream, z_coarse, weights_coarse, u, key, n_rays, n_samples, n_importance, npad,
                        z_new_out, z_fine_out);
-    return check_launch("importance_resample");
+    return check_launch(who);
+}
+
+int nerfmi_importance_resample(const float *z_coarse, const float *weights_coarse, const float *u, int n_rays,
+                               int n_samples, int n_importance, float *z_new_out, float *z_fine_out,
+                               nerfmi_stream_t stream) {
+    return importance_resample_impl("importance_resample", z_coarse, weights_coarse, u, DrawKey{0, 0, 0, 0}, n_rays, n_samples,
+                                    n_importance, z_new_out, z_fine_out, stream);
+}
+
+int nerfmi_importance_resample_philox(const float *z_coarse, const float *weights_coarse, uint64_t seed, uint64_t offset,
+                                      int n_rays, int n_samples, int n_importance, float *z_new_out, float *z_fine_out,
+                                      nerfmi_stream_t stream) {
+    return importance_resample_impl("importance_resample_philox", z_coarse, weights_coarse, nullptr, DrawKey{seed, offset, 2, 1},
+                                    n_rays, n_samples, n_importance, z_new_out, z_fine_out, stream);
 }
 
 }  // extern "C"

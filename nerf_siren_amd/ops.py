@@ -67,14 +67,24 @@ def version() -> int:
 
 
 # --------------------------------------------------------------------------- a2
-def sample_stratified(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand=None):
+def _u64(v):
+    return int(v) & (2 ** 64 - 1)
+
+
+def sample_stratified(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand=None, philox=None):
+    """philox = (seed, offset): draw the jitter in the kernel (segment 0 of that stream) instead of reading perturb_rand."""
     rays = _req(rays, "rays", (None, 8))
     n = rays.shape[0]
+    z = torch.empty((n, n_samples), device=rays.device, dtype=torch.float32)
+    if perturb > 0 and perturb_rand is None and philox is not None:
+        check(_lib.lib().nerfmi_sample_stratified_philox(ptr(rays), _u64(philox[0]), _u64(philox[1]), n, n_samples,
+                                                         int(bool(use_disp)), float(perturb), ptr(z), _stream(rays)),
+              "sample_stratified_philox")
+        return z
     if perturb > 0:
         perturb_rand = _req(perturb_rand, "perturb_rand", (n, n_samples))
         if perturb_rand is None:
             raise ValueError("perturb > 0 needs perturb_rand")
-    z = torch.empty((n, n_samples), device=rays.device, dtype=torch.float32)
     check(_lib.lib().nerfmi_sample_stratified(ptr(rays), ptr(perturb_rand) if perturb > 0 else None, n, n_samples,
                                               int(bool(use_disp)), float(perturb), ptr(z), _stream(rays)),
           "sample_stratified")
@@ -84,15 +94,22 @@ def sample_stratified(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand
 _DRAW_OFFSET = {}
 
 
+def next_draw_key(device):
+    """(seed, offset) of the next render_rays call on `device`: seed = torch.initial_seed() (torch.manual_seed controls
+    it), offset = a per-device call counter."""
+    offset = _DRAW_OFFSET.get(device, 0)
+    _DRAW_OFFSET[device] = offset + 1
+    return torch.initial_seed(), offset
+
+
 def render_draws(device, n_rays, S, F, perturb=True, noise=True, seed=None, offset=None):
     """The random draws of one render_rays call from ONE launch (nerfmi_render_draws): dict with 'perturb_rand' (N,S),
     'u' (N,F) when `perturb`, 'noise_coarse' (N,S), 'noise_fine' (N,S+F) when `noise` -- views of one allocation.
     seed defaults to torch.initial_seed() (torch.manual_seed controls it), offset to a per-device call counter."""
-    if seed is None:
-        seed = torch.initial_seed()
-    if offset is None:
-        offset = _DRAW_OFFSET.get(device, 0)
-        _DRAW_OFFSET[device] = offset + 1
+    if seed is None or offset is None:
+        k = next_draw_key(device)
+        seed = k[0] if seed is None else seed
+        offset = k[1] if offset is None else offset
     sizes = [n_rays * S if perturb else 0, n_rays * S if noise else 0, n_rays * F if perturb else 0,
              n_rays * (S + F) if (noise and F > 0) else 0]
     buf = torch.empty(sum(sizes), device=device, dtype=torch.float32)
@@ -100,7 +117,7 @@ def render_draws(device, n_rays, S, F, perturb=True, noise=True, seed=None, offs
     for n in sizes:
         segs.append(buf[off:off + n] if n else None)
         off += n
-    check(_lib.lib().nerfmi_render_draws(int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), sizes[0], ptr(segs[0]),
+    check(_lib.lib().nerfmi_render_draws(_u64(seed), _u64(offset), sizes[0], ptr(segs[0]),
                                          sizes[1], ptr(segs[1]), sizes[2], ptr(segs[2]), sizes[3], ptr(segs[3]),
                                          torch.cuda.current_stream(device).cuda_stream), "render_draws")
     out = {}
@@ -396,7 +413,10 @@ def siren_forward_rays_fast(packed, fast, rays, z, freq, phase, rays_per_cond, s
 
 
 # --------------------------------------------------------------------------- a8
-def composite(field, z, rays, noise=None, noise_std=0.0, white_back=False, sigma_only=False, want_weights=True):
+def composite(field, z, rays, noise=None, noise_std=0.0, white_back=False, sigma_only=False, want_weights=True,
+              philox=None):
+    """philox = (seed, offset, segment): draw the density noise in the kernel (segment 1 coarse / 3 fine) instead of reading
+    `noise`; composite_backward must be given the same triple."""
     rays = _req(rays, "rays", (None, 8))
     n = rays.shape[0]
     z = _req(z, "z", (n, None))
@@ -410,13 +430,19 @@ def composite(field, z, rays, noise=None, noise_std=0.0, white_back=False, sigma
     if not sigma_only:
         rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
         depth = torch.empty((n,), device=dev, dtype=torch.float32)
-    check(_lib.lib().nerfmi_composite(ptr(field), int(bool(sigma_only)), ptr(z), ptr(rays), ptr(noise),
-                                      float(noise_std), n, p, int(bool(white_back)), ptr(weights), ptr(rgb),
-                                      ptr(depth), ptr(opacity), _stream(rays)), "composite")
+    if noise is None and philox is not None and noise_std != 0:
+        check(_lib.lib().nerfmi_composite_philox(ptr(field), int(bool(sigma_only)), ptr(z), ptr(rays), _u64(philox[0]),
+                                                 _u64(philox[1]), int(philox[2]), float(noise_std), n, p,
+                                                 int(bool(white_back)), ptr(weights), ptr(rgb), ptr(depth), ptr(opacity),
+                                                 _stream(rays)), "composite_philox")
+    else:
+        check(_lib.lib().nerfmi_composite(ptr(field), int(bool(sigma_only)), ptr(z), ptr(rays), ptr(noise),
+                                          float(noise_std), n, p, int(bool(white_back)), ptr(weights), ptr(rgb),
+                                          ptr(depth), ptr(opacity), _stream(rays)), "composite")
     return weights, rgb, depth, opacity
 
 
-def composite_backward(field, z, rays, noise, noise_std, white_back, g_rgb, g_depth, g_opacity):
+def composite_backward(field, z, rays, noise, noise_std, white_back, g_rgb, g_depth, g_opacity, philox=None):
     rays = _req(rays, "rays", (None, 8))
     n = rays.shape[0]
     z = _req(z, "z", (n, None))
@@ -427,9 +453,15 @@ def composite_backward(field, z, rays, noise, noise_std, white_back, g_rgb, g_de
     g_depth = _req(g_depth, "g_depth", (n,)) if g_depth is not None else None
     g_opacity = _req(g_opacity, "g_opacity", (n,)) if g_opacity is not None else None
     grad_field = torch.empty((n * p, 4), device=rays.device, dtype=torch.float32)
-    check(_lib.lib().nerfmi_composite_backward(ptr(field), ptr(z), ptr(rays), ptr(noise), float(noise_std), n, p,
-                                               int(bool(white_back)), ptr(g_rgb), ptr(g_depth), ptr(g_opacity),
-                                               ptr(grad_field), _stream(rays)), "composite_backward")
+    if noise is None and philox is not None and noise_std != 0:
+        check(_lib.lib().nerfmi_composite_backward_philox(ptr(field), ptr(z), ptr(rays), _u64(philox[0]), _u64(philox[1]),
+                                                          int(philox[2]), float(noise_std), n, p, int(bool(white_back)),
+                                                          ptr(g_rgb), ptr(g_depth), ptr(g_opacity), ptr(grad_field),
+                                                          _stream(rays)), "composite_backward_philox")
+    else:
+        check(_lib.lib().nerfmi_composite_backward(ptr(field), ptr(z), ptr(rays), ptr(noise), float(noise_std), n, p,
+                                                   int(bool(white_back)), ptr(g_rgb), ptr(g_depth), ptr(g_opacity),
+                                                   ptr(grad_field), _stream(rays)), "composite_backward")
     return grad_field
 
 
@@ -501,15 +533,22 @@ def merge_sorted(za, zb):
     return out
 
 
-def importance_resample(z_coarse, weights_coarse, n_importance, u=None, want_new=False):
+def importance_resample(z_coarse, weights_coarse, n_importance, u=None, want_new=False, philox=None):
+    """u = None and philox = None: deterministic u = linspace(0, 1, F) (rendering.py:44); philox = (seed, offset): draw u in
+    the kernel (segment 2 of that stream)."""
     z_coarse = _req(z_coarse, "z_coarse", (None, None))
     n, s = z_coarse.shape
     weights_coarse = _req(weights_coarse, "weights_coarse", (n, s))
     u = _req(u, "u", (n, n_importance))
     z_fine = torch.empty((n, s + n_importance), device=z_coarse.device, dtype=torch.float32)
     z_new = torch.empty((n, n_importance), device=z_coarse.device, dtype=torch.float32) if want_new else None
-    check(_lib.lib().nerfmi_importance_resample(ptr(z_coarse), ptr(weights_coarse), ptr(u), n, s, n_importance,
-                                                ptr(z_new), ptr(z_fine), _stream(z_coarse)), "importance_resample")
+    if u is None and philox is not None:
+        check(_lib.lib().nerfmi_importance_resample_philox(ptr(z_coarse), ptr(weights_coarse), _u64(philox[0]), _u64(philox[1]),
+                                                           n, s, n_importance, ptr(z_new), ptr(z_fine), _stream(z_coarse)),
+              "importance_resample_philox")
+    else:
+        check(_lib.lib().nerfmi_importance_resample(ptr(z_coarse), ptr(weights_coarse), ptr(u), n, s, n_importance,
+                                                    ptr(z_new), ptr(z_fine), _stream(z_coarse)), "importance_resample")
     return (z_fine, z_new) if want_new else z_fine
 
 

@@ -104,9 +104,14 @@ class FieldRender(torch.autograd.Function):
             else:
                 field, saved = ops.nerf_forward_rays(packed, rays, z, sigma_only=False, save=True)
             ctx.fast = model.packed_fast() if _MATH == "bf16x3" else None
-        weights, rgb, depth, opacity = ops.composite(field, z, rays, noise, noise_std, white_back)
+        # noise: the injected randn tensor, a (seed, offset, segment) Philox key (drawn inside the compositor, forward and
+        # backward alike) or None
+        philox = noise if isinstance(noise, tuple) else None
+        noise = None if philox is not None else noise
+        weights, rgb, depth, opacity = ops.composite(field, z, rays, noise, noise_std, white_back, philox=philox)
         ctx.save_for_backward(rays, z, noise if noise is not None else rays.new_empty(0), field, saved, packed)
         ctx.cfg = (noise is not None, float(noise_std), bool(white_back), siren)
+        ctx.philox = philox
         ctx.model = model
         ctx.mark_non_differentiable(weights)
         ctx.set_materialize_grads(False)        # absent d/d(depth, opacity) arrive as None -> NULL in the C ABI
@@ -120,7 +125,7 @@ class FieldRender(torch.autograd.Function):
         if g_rgb is None and g_depth is None and g_opacity is None:
             return (None,) * (6 + n_params)
         grad_field = ops.composite_backward(field, z, rays, noise if has_noise else None, noise_std, white_back,
-                                            g_rgb, g_depth, g_opacity)
+                                            g_rgb, g_depth, g_opacity, philox=ctx.philox)
         out = _claim_grad_target(ctx.model, rays.device)
         if siren:
             grads = ops.siren_backward(packed, saved, grad_field, ctx.model.frequencies, z.numel(), grads=out)
@@ -176,27 +181,12 @@ class EmbeddedField(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
-def _rng(rng, key, shape, device, kind):
+def _rng(rng, key, shape):
+    """The injected draw `key`, shape-checked, or None."""
     t = None if rng is None else rng.get(key)
-    if t is None:
-        raise KeyError(key)                     # render_rays fills every draw it needs before asking for it
-    if tuple(t.shape) != tuple(shape):
+    if t is not None and tuple(t.shape) != tuple(shape):
         raise ValueError(f"rng['{key}'] has shape {tuple(t.shape)}, expected {tuple(shape)}")
     return t
-
-
-def _complete_draws(rng, device, N, S, F, perturb, noise_std):
-    """The reference's draws (rendering.py:221 rand, :170 randn, :47 rand, :170 randn) that the caller did not inject,
-    all from ONE Philox launch (ops.render_draws) instead of up to four aten distribution launches."""
-    have = rng or {}
-    need_p = (perturb > 0 and "perturb_rand" not in have) or (perturb != 0 and F > 0 and "u" not in have
-                                                               and "z_fine" not in have)
-    need_n = noise_std != 0 and (rng is None or "noise_coarse" not in rng or (F > 0 and "noise_fine" not in rng))
-    if not (need_p or need_n):
-        return rng
-    drawn = ops.render_draws(device, N, S, F, perturb=need_p, noise=need_n)
-    drawn.update(rng or {})                     # injected tensors win
-    return drawn
 
 
 def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=0, noise_std=1, N_importance=0,
@@ -209,8 +199,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     chunk: accepted for compatibility; the fused kernels need no point chunking.
     rng (keyword-only, optional): dict of injected random draws in the reference's
     order -- 'perturb_rand' (N,S) [rendering.py:221], 'noise_coarse' (N,S) [:170],
-    'u' (N,F) [:47], 'noise_fine' (N,S+F); missing entries are drawn on the device by ONE Philox launch
-    (ops.render_draws; torch.manual_seed sets the key).  'z_fine' (N,S+F), when given,
+    'u' (N,F) [:47], 'noise_fine' (N,S+F); missing entries are drawn INSIDE the consuming kernels from
+    Philox streams keyed by torch.manual_seed (ops.next_draw_key; ops.render_draws materialises the same streams).  'z_fine' (N,S+F), when given,
     replaces the merged depths of :247 (parity tests condition the fine pass on the reference's own depths:
     sample_pdf is ill-conditioned in ~zero-weight bins).
     aux (keyword-only, optional): a dict that receives the intermediates 'z_coarse', 'weights_coarse', 'z_fine'.
@@ -227,26 +217,32 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     model_coarse = models[0]
     train = torch.is_grad_enabled() and any(p.requires_grad for m in models for p in m.parameters())
 
-    rng = _complete_draws(rng, dev, N, S, F, perturb, noise_std)
-    pr = _rng(rng, "perturb_rand", (N, S), dev, "rand") if perturb > 0 else None
-    z = ops.sample_stratified(rays, S, use_disp, float(perturb), pr)
+    # Random draws (rendering.py:221 rand, :170 randn, :47 rand, :170 randn): injected tensors win (parity tests); every
+    # other draw is made INSIDE the consuming kernel from one Philox key per call (seed = torch.initial_seed(), offset =
+    # a per-device call counter) -- no aten distribution launches, no tensors of draws.
+    draw_key = ops.next_draw_key(dev) if (perturb != 0 or noise_std != 0) else None
+    pr = _rng(rng, "perturb_rand", (N, S)) if perturb > 0 else None
+    z = ops.sample_stratified(rays, S, use_disp, float(perturb), pr, philox=draw_key)
 
-    def noise_for(key, P):
+    def noise_for(key, P, seg):
         # rendering.py:170 draws randn even when noise_std == 0 (result x0); the
         # native path skips the draw -- identical outputs.
-        return _rng(rng, key, (N, P), dev, "randn") if noise_std != 0 else None
+        if noise_std == 0:
+            return None, None
+        t = _rng(rng, key, (N, P))
+        return (t, None) if t is not None else (None, (draw_key[0], draw_key[1], seg))
 
-    def full_pass(model, zz, key):
-        noise = noise_for(key, zz.shape[1])
+    def full_pass(model, zz, key, seg):
+        noise, philox = noise_for(key, zz.shape[1], seg)
         if train and any(p.requires_grad for p in model.param_list()):
-            rgb, depth, opacity, weights = FieldRender.apply(model, rays, zz, noise, float(noise_std),
-                                                            bool(white_back), *model.param_list())
+            rgb, depth, opacity, weights = FieldRender.apply(model, rays, zz, noise if philox is None else philox,
+                                                            float(noise_std), bool(white_back), *model.param_list())
         elif hasattr(model, "field_rays"):                     # FiLM-SIREN adapter (nerf.SirenField)
             field = model.field_rays(rays, zz, sigma_only=False)
-            weights, rgb, depth, opacity = ops.composite(field, zz, rays, noise, noise_std, white_back)
+            weights, rgb, depth, opacity = ops.composite(field, zz, rays, noise, noise_std, white_back, philox=philox)
         else:
             field = _field_infer(model, rays, zz, False)
-            weights, rgb, depth, opacity = ops.composite(field, zz, rays, noise, noise_std, white_back)
+            weights, rgb, depth, opacity = ops.composite(field, zz, rays, noise, noise_std, white_back, philox=philox)
         return rgb, depth, opacity, weights
 
     if test_time:
@@ -255,23 +251,23 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
             sig = model_coarse.field_rays(rays, z, sigma_only=True)
         else:
             sig = _field_infer(model_coarse, rays, z, True)
-        weights_coarse, _, _, op = ops.composite(sig, z, rays, noise_for("noise_coarse", S), noise_std, white_back,
-                                                 sigma_only=True)
+        noise, philox = noise_for("noise_coarse", S, 1)
+        weights_coarse, _, _, op = ops.composite(sig, z, rays, noise, noise_std, white_back, sigma_only=True, philox=philox)
         result = {"opacity_coarse": op}
     else:
-        rgb, depth, op, weights_coarse = full_pass(model_coarse, z, "noise_coarse")
+        rgb, depth, op, weights_coarse = full_pass(model_coarse, z, "noise_coarse", 1)
         result = {"rgb_coarse": rgb, "depth_coarse": depth, "opacity_coarse": op}
 
     if F > 0:
-        u = _rng(rng, "u", (N, F), dev, "rand") if perturb != 0 else None     # det = (perturb == 0), :243
+        u = _rng(rng, "u", (N, F)) if perturb != 0 else None                   # det = (perturb == 0), :243
         z_fine = None if rng is None else rng.get("z_fine")
         if z_fine is None:
-            z_fine = ops.importance_resample(z, weights_coarse, F, u)
+            z_fine = ops.importance_resample(z, weights_coarse, F, u, philox=draw_key if perturb != 0 else None)
         elif tuple(z_fine.shape) != (N, S + F):
             raise ValueError(f"rng['z_fine'] has shape {tuple(z_fine.shape)}, expected {(N, S + F)}")
         if aux is not None:
             aux.update(z_coarse=z, weights_coarse=weights_coarse, z_fine=z_fine)
-        rgb, depth, op, _ = full_pass(models[1], z_fine, "noise_fine")
+        rgb, depth, op, _ = full_pass(models[1], z_fine, "noise_fine", 3)
         result["rgb_fine"] = rgb
         result["depth_fine"] = depth
         result["opacity_fine"] = op

@@ -1685,16 +1685,19 @@ def test_render_draws_philox(ops, dev):
 
 
 def test_render_rays_draws_on_device(dev, models):
-    """Without injected draws render_rays takes them from ONE Philox launch keyed by torch.manual_seed: the same seed
-    and call count give the same image, a later call different noise; injected draws still win."""
+    """Without injected draws render_rays draws INSIDE its kernels (sampler jitter, compositor noise forward AND
+    backward, resampling u) from Philox streams keyed by torch.manual_seed and a per-device call counter: the same seed and
+    call count give the same image, a later call different noise, and -- the strong check -- the image AND the parameter
+    gradients are bit-identical to a run that is handed the same streams as tensors (nerfmi_render_draws)."""
     from nerf_siren_amd import Embedding, render_rays
     from nerf_siren_amd import ops as o
     _, ms = models
     emb = [Embedding(3, 10), Embedding(3, 4)]
-    rays = T(synth.blender_rays(200, 15), dev)
+    n = 200
+    rays = T(synth.blender_rays(n, 15), dev)
 
-    def run(**kw):
-        with torch.no_grad():
+    def run(grad=False, **kw):
+        with (torch.enable_grad() if grad else torch.no_grad()):
             return render_rays(ms, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, True, False, **kw)
     torch.manual_seed(77)
     o._DRAW_OFFSET.clear()
@@ -1703,10 +1706,38 @@ def test_render_rays_draws_on_device(dev, models):
     o._DRAW_OFFSET.clear()
     c = run()
     assert torch.equal(a["rgb_fine"], c["rgb_fine"]) and not torch.equal(a["rgb_fine"], b["rgb_fine"])
-    assert torch.isfinite(a["rgb_fine"]).all()
-    inj = o.render_draws(dev, 200, 64, 64, seed=3, offset=9)
-    d, e = run(rng=inj), run(rng=dict(inj))
-    assert torch.equal(d["rgb_fine"], e["rgb_fine"])
+    assert all(torch.isfinite(v).all() for v in a.values())
+    inj = o.render_draws(dev, n, 64, 64, seed=77, offset=0)               # the streams of the first call, materialised
+    d = run(rng=inj)
+    for k in a:
+        assert torch.equal(a[k], d[k]), k
+    # test_time (sigma-only compositor) draws the same coarse noise
+    torch.manual_seed(77)
+    o._DRAW_OFFSET.clear()
+    with torch.no_grad():
+        t1 = render_rays(ms, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, True, True)
+        t2 = render_rays(ms, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, True, True, rng=inj)
+    for k in t1:
+        assert torch.equal(t1[k], t2[k]), k
+    # training: the compositor's backward regenerates the forward's noise from the key
+    grads = []
+    for kw in ({}, {"rng": inj}):
+        torch.manual_seed(77)
+        o._DRAW_OFFSET.clear()
+        for m in ms:
+            m.zero_grad()
+        r = run(grad=True, **kw)
+        (r["rgb_coarse"].square().mean() + r["rgb_fine"].square().mean() + 0.1 * r["depth_fine"].mean()).backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for m in ms for p in m.param_list()]).clone())
+    assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
+    for m in ms:
+        m.zero_grad()
+    # partial injection: the other draws still come from the key
+    torch.manual_seed(77)
+    o._DRAW_OFFSET.clear()
+    e = run(rng={"u": inj["u"]})
+    for k in a:
+        assert torch.equal(a[k], e[k]), k
 
 
 def test_chunked_batch_under_flat_grad_reducer(dev):
