@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Stability soak (GPU box): N training steps on the teacher scene with the fused loss/optimizer, alternating the
 exact-fp32 and the opt-in split-bf16 math every 100 steps; checks finiteness, a falling loss and flat memory.
-usage: python tools/soak.py [steps]"""
+usage: python tools/soak.py [steps] [nerf|siren]   (siren: the FiLM-SIREN field through the same loop, in-kernel draws)"""
 import json
 import os
 import sys
@@ -17,24 +17,32 @@ from nerf_siren_amd.parallel import FlatGradAllReduce
 from nerf_siren_amd.training import FusedAdam, FusedMSELoss
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+FIELD = sys.argv[2] if len(sys.argv) > 2 else "nerf"
 dev = torch.device("cuda:0")
 g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g15_psnr.npz"))
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)          # noqa: E731
 rays, tgt, val_rays, val_tgt = T(g["rays"]), T(g["target"]), T(g["val_rays"]), T(g["val_target"])
 ms = []
 for seed in (11, 12):
-    m = NeRF()
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
+    if FIELD == "siren":
+        from nerf_siren_amd import SemanticNeRF, SirenField
+        sm = SemanticNeRF()
+        sm.load_state_dict({k: torch.from_numpy(v) for k, v in synth.siren_params(seed).items()})
+        m = SirenField(sm, torch.from_numpy(synth.hash_normal((1, 2304), 10 + seed) * 0.3),
+                       torch.from_numpy(synth.hash_normal((1, 2304), 20 + seed)))
+    else:
+        m = NeRF()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
     ms.append(m.to(dev))
 emb = [Embedding(3, 10), Embedding(3, 4)]
-opt, loss_fn, red = FusedAdam(ms, lr=5e-4), FusedMSELoss(unit_grad=True), FlatGradAllReduce(ms, 1)
+opt, loss_fn, red = FusedAdam(ms, lr=5e-4 if FIELD == "nerf" else 5e-5), FusedMSELoss(unit_grad=True), FlatGradAllReduce(ms, 1)
 sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[steps // 2, 3 * steps // 4], gamma=0.5)
 losses, mem = [], []
 t0 = time.perf_counter()
 for step in range(steps):
-    nerf_siren_amd.set_math("bf16x3" if (step // 100) % 2 else "fp32")
+    nerf_siren_amd.set_math("bf16x3" if (step // 100) % 2 and FIELD == "nerf" else "fp32")
     idx = torch.randint(0, rays.shape[0], (1024,), device=dev)
-    res = render_rays(ms, emb, rays[idx], 64, False, 1.0, 0.0, 64, 1 << 15, True, False)
+    res = render_rays(ms, emb, rays[idx], 64, False, 1.0, 0.0 if FIELD == "nerf" else 0.5, 64, 1 << 15, True, False)
     loss = loss_fn(res, tgt[idx])
     opt.zero_grad()
     loss.backward()
