@@ -35,6 +35,28 @@ CFG_LONG = dict(res=64, n_train_views=24, val_res=400, batch=1024, steps=1500, e
 view_rays = synth.view_rays
 
 
+class AnalyticScene(torch.nn.Module):
+    """--scene spheres: a crisp, learnable teacher for the long protocol -- three coloured soft-edged spheres and a slab,
+    evaluated on the raw xyz channels (the first three) of the embedded input.  It stands where the reference expects a NeRF:
+    forward(x, sigma_only) -> (B,4) [rgb, sigma] / (B,1), so the reference's own render_rays renders the target images."""
+    CENTRES = torch.tensor([[0.55, 0.25, 0.10], [-0.60, -0.35, 0.25], [0.05, -0.55, -0.45]])
+    RADII = torch.tensor([0.55, 0.45, 0.40])
+    COLOURS = torch.tensor([[0.90, 0.20, 0.15], [0.15, 0.75, 0.25], [0.20, 0.30, 0.90]])
+
+    def forward(self, x, sigma_only=False):
+        p = x[:, :3]
+        d = torch.linalg.norm(p[:, None, :] - self.CENTRES[None], dim=-1)                   # (B,3)
+        occ = torch.sigmoid((self.RADII[None] - d) * 25.0)                                    # soft membership
+        slab = torch.sigmoid((0.9 - p[:, :2].abs().max(-1).values) * 25.0) * torch.sigmoid((-0.75 - p[:, 2]) * 25.0) \
+            * torch.sigmoid((p[:, 2] + 0.95) * 25.0)
+        w = torch.cat([occ, slab[:, None]], -1)                                               # (B,4)
+        cols = torch.cat([self.COLOURS, torch.tensor([[0.85, 0.80, 0.55]])], 0)
+        stripes = 0.75 + 0.25 * torch.sin(6.0 * p[:, 0:1]) * torch.sin(6.0 * p[:, 1:2])       # mid-frequency texture
+        rgb = (w[:, :, None] * cols[None]).sum(1) / w.sum(-1, keepdim=True).clamp_min(1e-6) * stripes
+        sigma = 40.0 * w.max(-1, keepdim=True).values
+        return sigma if sigma_only else torch.cat([rgb.clamp(0, 1), sigma], -1)
+
+
 step_rng = synth.psnr_step_rng            # shared with tests/test_gpu_parity.py::test_psnr_parity
 batch_indices = synth.psnr_batch_indices
 
@@ -64,7 +86,9 @@ def main():
         m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
         return m
 
-    teacher = [model(synth.nerf_params(7, sigma_bias=-0.5)), model(synth.nerf_params(8, sigma_bias=0.5))]
+    spheres = "spheres" in sys.argv
+    teacher = [AnalyticScene(), AnalyticScene()] if spheres else \
+        [model(synth.nerf_params(7, sigma_bias=-0.5)), model(synth.nerf_params(8, sigma_bias=0.5))]
     rays = np.concatenate([view_rays(c["res"], 300 + v) for v in range(c["n_train_views"])], 0)
     val_rays = view_rays(c.get("val_res", c["res"]), 399)
 
@@ -109,7 +133,8 @@ def main():
             sched.step()
         losses.append(float(loss))
     if long:
-        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g19_psnr_long.npz"), target=tgt, val_target=val_tgt,
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g19s_psnr_spheres.npz" if spheres else "g19_psnr_long.npz"),
+                            target=tgt, val_target=val_tgt,
                             psnr=np.array(psnr, np.float32), losses=np.array(losses, np.float32),
                             **{"cfg_" + k: v for k, v in c.items()})
     else:
