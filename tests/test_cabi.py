@@ -62,6 +62,26 @@ def test_argument_validation_without_gpu(libpath):
     assert l.nerfmi_nerf_backward_rays_fast(None, None, 4, 8, None, None, None, None, None) == -1
     assert l.nerfmi_siren_forward_rays_fast(None, None, None, None, None, None, 0, 8, 1, 0, None, None) == 0
     assert l.nerfmi_nerf_fast_bytes() > 3 * 2 * 1100000 and l.nerfmi_siren_fast_bytes() > 3 * 2 * 500000
+    # round 2: FiLM-SIREN training path, module-API training forward, in-kernel draws, EG3D sample grid
+    assert l.nerfmi_siren_forward_rays_train(None, None, None, None, None, 4, 8, 4, None, None, None) == -1
+    assert b"null" in l.nerfmi_last_error()
+    assert l.nerfmi_siren_forward_rays_train(None, None, None, None, None, 0, 8, 1, None, None, None) == 0   # empty
+    assert l.nerfmi_siren_forward_points_train(None, None, None, None, None, 5, 0, None, None, None) == -1   # per_cond >= 1
+    assert l.nerfmi_siren_backward(None, None, None, None, 0, 1, None, None, None) == -1                      # n_points >= 1
+    assert l.nerfmi_siren_backward(None, None, None, None, 64, 64, None, None, None) == -1
+    assert l.nerfmi_siren_saved_floats(64) == 2444 * (64 + 32)                     # csrc/siren_core.h SIREN_SAVED_ROWS + dump tile
+    assert l.nerfmi_siren_backward_workspace_floats(64) > 2312 * (64 + 32)
+    assert l.nerfmi_siren_packed_floats() == 1076736                               # forward + small + transposed images + stream tail (siren_core.h)
+    assert l.nerfmi_nerf_forward_embedded_train(None, None, 8, None, None, None) == -1
+    assert l.nerfmi_nerf_forward_embedded_train(None, None, 0, None, None, None) == 0
+    assert l.nerfmi_render_draws(1, 2, 16, None, 0, None, 0, None, 0, None, None) == -1 and b"segment 0" in l.nerfmi_last_error()
+    assert l.nerfmi_render_draws(1, 2, 0, None, 0, None, 0, None, 0, None, None) == 0
+    assert l.nerfmi_sample_stratified_philox(None, 1, 2, 4, 64, 0, 1.0, None, None) == -1
+    assert l.nerfmi_composite_philox(None, 0, None, None, 1, 2, 2, 1.0, 4, 64, 0, None, None, None, None, None) == -1
+    assert b"segment" in l.nerfmi_last_error()                                     # 1 (coarse) or 3 (fine) only
+    assert l.nerfmi_composite_backward_philox(None, None, None, 1, 2, 3, 1.0, 0, 64, 0, None, None, None, None, None) == 0
+    assert l.nerfmi_importance_resample_philox(None, None, 1, 2, 4, 2, 64, None, None, None) == -1          # S >= 3
+    assert l.nerfmi_create_samples(1, 0.0, 0.0, 0.0, 1.0, None, None) == -1 and l.nerfmi_create_samples(8, 0.0, 0.0, 0.0, 1.0, None, None) == -1
 
 
 def test_python_api_mirrors_reference_signature():
