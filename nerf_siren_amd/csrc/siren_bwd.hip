@@ -183,7 +183,7 @@ siren_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__rest
     const int chunk = blockIdx.x - T.wg0;
     switch (T.kind) {
         case 0: dw_task<2, 8, 4, 1, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 256
-        case 1: dw_task<2, 2, 4, 1, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 64
+        case 1: dw_task<2, 1, 4, 1, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 32 (3 real columns)
         default: dw_task<1, 2, 1, 4, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;  // 32 x 256
     }
 #ifdef NERFMI_TIMING
@@ -192,7 +192,7 @@ siren_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__rest
 }
 
 static const int SKIND_JB[3] = {8, 8, 1};
-static const int SKIND_KB[3] = {8, 2, 8};
+static const int SKIND_KB[3] = {8, 1, 8};
 
 static DwPlan siren_plan(int64_t ld) {
     DwPlan P;
@@ -210,8 +210,10 @@ static DwPlan siren_plan(int64_t ld) {
     add(2, SW_DRGB, 3, SS_HC, 256, 20, 0, 256, 21);                                             // color_layer_linear.0
     add(2, SW_DSIG, 1, SS_H + 256 * 7, 256, 16, 0, 256, 17);                                    // final_layer
     P.n_tasks = n;
-    // 8 x 28 + 2 x 10 + 2 x 6 = 256 workgroups, one per CU (see mlp_bwd.hip make_plan for how the shares were chosen)
-    static const int chunks_default[3] = {28, 10, 6};
+    // 8 x 29 + 2 x 6 + 2 x 6 = 256 workgroups, one per CU (shares from per-task workgroup stamps, tools/exp_siren_dw_timing.py).
+    // The two K = 3 tasks (network.0: X = xyz; colour layer: dir columns) use the narrowest B tile there is, 32 columns:
+    // as 64-column tasks they kept 20 workgroups busy multiplying zero padding.
+    static const int chunks_default[3] = {29, 6, 6};
     const int *chunks = chunks_default;
     int chunks_env[3];
     if (const char *e = getenv("NERFMI_SIREN_DW_CHUNKS")) {     // experiments (tools/exp_siren_dw_timing.py): "c0,c1,c2"
