@@ -6,7 +6,7 @@
 //  1. siren_backward_chain_kernel -- the dX chain.  Same register-resident scheme as the NeRF chain (mlp_bwd.hip): a
 //     wave owns 32 points, dZ_l^T lives in the accumulator layout and is the B operand of
 //     dH_{l-1}^T = W_l^T . dZ_l^T (A = the transposed packed image).  The activation derivative is
-//         d sin(fr * pre + ph) / d pre = fr * cos(arg),   |cos(arg)| = sqrt((1 - s)(1 + s)),  s = the saved sine,
+//         d sin(fr * pre + ph) / d pre = fr * cos(arg),   |cos(arg)| = sqrt(1 - s^2),  s = the saved sine,
 //     with the sign from the forward's bitmask: nothing but the sines is re-read.  Every dZ_l goes to the workspace as
 //     a tile-major image.
 //  2. dW_l = dZ_l^T . X_l: the NeRF dW GEMM (dw_core.h) on a 12-task plan of exactly 256 workgroups.
@@ -51,7 +51,7 @@ __device__ __forceinline__ f32x4 film_grad(f32x4 dh, const f32x16 &s, const unsi
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const float sv = s[4 * q + t];
-        const float c2 = (1.0f - sv) * (1.0f + sv);
+        const float c2 = __builtin_fmaf(-sv, sv, 1.0f);         // cos^2 = 1 - s^2, one rounding (no worse than the sine's own)
         // the raw v_sqrt_f32 (1 ulp): sqrtf() is expanded to the correctly rounded sequence (scale, refine, classify:
         // ~14 instructions) which tripled this epilogue's vector work -- and |cos| feeds a product, not a parity check
         const float ca = __builtin_amdgcn_sqrtf(fmaxf(c2, 0.f));
