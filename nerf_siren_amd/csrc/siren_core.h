@@ -133,12 +133,14 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
 #pragma unroll
                 for (int t = 0; t < 4; ++t) fr[t] = __fadd_rn(__fmul_rn(f[t], 15.0f), 30.0f);      // nerf.py:202
             }
-            const int sh = 16 * (jb & 1) + 4 * q;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 unsigned jbits;
                 c[t] = sin_pi(__fadd_rn(__fmul_rn(fr[t], c[t]), s[t]), jbits);                      // nerf.py:151
-                if (SAVE) mk[jb >> 1] |= (jbits & 1u) << (sh + t);                                  // sign of cos(arg)
+                // sign of cos(arg) = parity of j: funnel-shifted into the mask word from the top, ONE instruction per value
+                // (v_alignbit: {jbits, mk} >> 1).  After the 32 insertions of blocks 2w, 2w+1 -- always in the order q, t --
+                // value (jb, q, t) sits at bit 16*(jb&1) + 4q + t, the layout the chain kernel reads.
+                if (SAVE) mk[jb >> 1] = __builtin_amdgcn_alignbit(jbits, mk[jb >> 1], 1);
             }
             if (SAVE) store_slice(S, (layer < 8 ? SS_H + 256 * layer : SS_HC) + 32 * jb, q, c);
             return c;
