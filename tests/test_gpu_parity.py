@@ -1453,6 +1453,62 @@ def test_two_rank_hip_gradients_match_single_rank(dev, overlap):
     assert float(((got[0][1] - ref_p).abs() > 1e-6).float().mean()) < 1e-3
 
 
+def _rccl_worker(port, n, overlap, q):
+    import torch.distributed as dist
+    from nerf_siren_amd.parallel import FlatGradAllReduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    rays, rng, tgt = _ddp_batch(n)
+    out = []
+    for use_reducer in (False, True):
+        models = _ddp_models(dev)
+        # world_size=2 forces the collective code path on the one-rank RCCL group (a SUM over one rank is the identity)
+        reducer = FlatGradAllReduce(models, 2, overlap=overlap) if use_reducer else None
+        for _ in range(3):                                    # repeated passes: the works dict is drained every step
+            for m in models:
+                for p in m.param_list():
+                    p.grad = None
+            _ddp_step(models, dev, rays, rng, tgt, 0, n).backward()
+            if reducer is not None:
+                bufs = reducer.all_reduce(average=False)
+                assert len(bufs) == 1 and bufs[0].data_ptr() == reducer.joint.data_ptr()
+        out.append(torch.cat([p.grad.reshape(-1) for m in models for p in m.param_list()]).cpu().numpy())
+    t = torch.ones(4, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    q.put((out[0], out[1], t.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("overlap", [False, True])
+def test_rccl_backend_reducer_on_one_rank(dev, overlap):
+    """The reducer on the backend the bench runs on (RCCL, `nccl`): a one-rank group on this box's GPU, the collective
+    path forced.  The in-place SUM over one rank is the identity, so the gradients must be BIT-equal to a plain
+    backward -- which they are only if RCCL's stream waits for the gradient kernels enqueued by the autograd thread
+    (overlap=True launches the fine model's all-reduce from inside the backward) and the compute stream waits for the
+    collective before the gradients are read."""
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, 96, overlap, q))
+    p.start()
+    plain, reduced, ones = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    assert np.array_equal(ones, np.ones(4, np.float32))
+    assert np.abs(plain).max() > 0 and np.array_equal(plain, reduced)
+
+
 # --------------------------------------------------------------------------- f1 / f3 against the reference's own outputs
 def test_ray_generation_vs_reference_fixture(golden, ops, dev):
     """The HIP ray-generation kernels against datasets/ray_utils.py:5-93 itself (fixture g20, generated by running the
