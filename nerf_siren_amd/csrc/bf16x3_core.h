@@ -6,6 +6,8 @@
 namespace nerfmi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 // Fast image: [forward layers' units][transposed (backward) layers' units][stream tail]; a unit = 3 x 1 KiB.
 constexpr int FAST_FWD_UNITS = OFF_SMALL / 512;
@@ -33,15 +35,20 @@ struct FastStage {
 };
 
 // Exact three-way split of TWO fp32 values into packed bf16 words (low half = x0's term): w[i] = {bf16_i(x0), bf16_i(x1)}.
-// Written with explicit instructions: the compiler otherwise vectorises the subtractions into v_pk_add_f32, and
+// Mostly written with explicit instructions: the compiler otherwise vectorises the subtractions into v_pk_add_f32, and
 // packed-fp32 instructions do NOT overlap with bf16 MFMAs (tools/ubench/mfma_valu.hip: 58 cycles for two) while
 // plain VALU instructions do (about five per 32-cycle MFMA).
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&w)[3]) {
     float r0 = x0, r1 = x1;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        unsigned p;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(r0), "v"(r1));
+        // the conversion through the compiler, NOT inline asm: its result is an MFMA B operand, and gfx950 needs two wait
+        // states between a VALU write and an MFMA read of the same register.  The hazard recogniser does not look inside
+        // inline asm, so an asm v_cvt_pk_bf16_f32 scheduled right in front of its MFMA handed the matrix core the
+        // register's STALE contents (round 2: scattered garbage / NaN in the FiLM-SIREN split-bf16 kernel, depending on
+        // whether the s_waitcnt in between happened to stall).  The shift / mask / subtract stay asm (they feed only
+        // vector instructions): left to the compiler they become v_pk_add_f32, which does not overlap with the MFMAs.
+        const unsigned p = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
         w[i] = p;
         if (i < 2) {
             float f0, f1;

@@ -106,12 +106,17 @@ siren_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__re
         const int r = 2 * pr;
         const int u = 256 * layer + 32 * kb + 8 * (r >> 2) + (r & 3);
         const float2 f = *reinterpret_cast<const float2 *>(fq + u), s = *reinterpret_cast<const float2 *>(ph + u);
-        // sin_cw, not the cheaper sin_pi of the fp32 kernels: with sin_pi in this hook the kernel returned load-dependent
-        // garbage / NaN in scattered lanes of the colour branch on MI355X (n = 1024 rays: half the points; bisected on
-        // the GPU with tools/dbg_siren_fast.py, cause not found -- the ISA's register allocation and LDS ring check
-        // out), while the same build with sin_cw agrees with the fp32 kernel to 2e-6 on every point.
+        // sin_pi as in the fp32 kernels.  (Round 2 first saw scattered garbage / NaN with it here and fell back to sin_cw;
+        // the cause was not the sine but an asm bf16 conversion in split_pair scheduled right in front of its MFMA --
+        // bf16x3_core.h, tools/hazard_scan.py -- which this instruction mix happened to expose.)
+#ifndef NERFMI_EXP_FAST_SINCW
+        unsigned jb0, jb1;
+        x0 = sin_pi(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.x, 15.0f), 30.0f), x0), s.x), jb0);
+        x1 = sin_pi(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.y, 15.0f), 30.0f), x1), s.y), jb1);
+#else
         x0 = sin_cw(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.x, 15.0f), 30.0f), x0), s.x));
         x1 = sin_cw(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.y, 15.0f), 30.0f), x1), s.y));
+#endif
     };
     auto film_hook = [&film](int layer) {
         return [&film, layer](int kb, int pr, float &x0, float &x1) { film(layer, kb, pr, x0, x1); };

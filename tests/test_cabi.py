@@ -119,3 +119,40 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+
+
+def _hazard_scan():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hazard_scan", os.path.join(ROOT, "tools", "hazard_scan.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_hazard_scanner_recognises_the_pattern():
+    hs = _hazard_scan()
+    bad = """
+0000000000001000 <k>:
+\tv_cvt_pk_bf16_f32 v137, v28, v38
+\ts_waitcnt lgkmcnt(3)
+\tv_mfma_f32_32x32x16_bf16 a[240:255], v[30:33], v[136:139], a[240:255]
+"""
+    ok = bad.replace("s_waitcnt lgkmcnt(3)", "s_nop 1")
+    far = bad.replace("s_waitcnt lgkmcnt(3)", "s_waitcnt lgkmcnt(3)\n\tv_add_f32_e32 v1, v2, v3")
+    assert len(hs.scan_disassembly(bad)[3]) == 1 and hs.scan_disassembly(bad)[3][0][1] == 1
+    assert hs.scan_disassembly(ok)[3] == [] and hs.scan_disassembly(far)[3] == []
+
+
+def test_no_valu_write_to_mfma_read_hazard_in_the_built_kernels(libpath):
+    """gfx950 needs two wait states between a vector instruction's write of a VGPR and an MFMA's read of it.  The
+    compiler pads its own instructions but not inline asm (csrc/bf16x3_core.h split_pair used to convert through asm and
+    one kernel instance read a stale B operand): scan every built code object, any hit is a bug."""
+    hs = _hazard_scan()
+    objs = hs.product_objects()
+    assert len(objs) >= 10
+    mfmas = 0
+    for o in objs:
+        for kernels, n_ins, n_mfma, hits in hs.scan_file(o):
+            assert not hits, (os.path.basename(o), hits[:3])
+            mfmas += n_mfma
+    assert mfmas > 100000                      # the MLP kernels were really disassembled
