@@ -438,12 +438,16 @@ def main():
             k_t = timer.mean_ms("siren_forward_rays_train")
             d_i = timed(make_step(sm, "infer"), ks, kw)
             k_i = timer.mean_ms("siren_forward_rays")
+            nerf_siren_amd.set_math("bf16x3")                     # the opt-in split-bf16 inference kernel of the same field
+            d_f = timed(make_step(sm, "infer"), ks, kw)
+            nerf_siren_amd.set_math("fp32")
             fl = B * 128 * FLOP_SIREN
             extra["siren"] = {
                 "workload": f"configs[1] with the FiLM-SIREN field (9 FiLM layers x 256, 529 156 parameters) coarse+fine, "
                             f"batch_size={B}",
                 "train_ms_per_step": d_t / ks * 1e3, "train_value": B * 192 * ks / d_t,
                 "infer_ms_per_step": d_i / ks * 1e3, "infer_value": B * 192 * ks / d_i, "unit": "ray-samples/s",
+                "opt_in_infer": {"math": "bf16x3", "ms_per_step": d_f / ks * 1e3, "value": B * 192 * ks / d_f},
                 "roofline": {"bound": "mfma", "kernel": "siren_forward_kernel<true,false,false> (fine pass, 128 samples/ray, "
                              "inference)", "achieved": fl / (k_i * 1e-3) / 1e12, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                              "frac": fl / (k_i * 1e-3) / 1e12 / PEAK_F32_MFMA, "flops_per_launch": fl, "avg_launch_ms": k_i,

@@ -812,7 +812,7 @@ def test_eg3d_ray_limits_box_and_auto(golden, dev, osg):
 
 
 # --------------------------------------------------------------------------- PSNR parity (metric: "+ PSNR")
-def _psnr_protocol(g, dev, impl):
+def _psnr_protocol(g, dev, impl, field="nerf"):
     """Teacher-scene protocol: the same Adam steps the reference ran on CPU
     (tools/make_psnr_golden.py: same teacher images, same batches, same injected random draws, same initial weights,
     same learning-rate schedule) on the HIP path -> validation-PSNR trajectory."""
@@ -823,8 +823,15 @@ def _psnr_protocol(g, dev, impl):
     steps, every = int(g["cfg_steps"]), int(g["cfg_eval_every"])
     ms = []
     for seed in (11, 12):
-        m = NeRF()
-        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
+        if field == "siren":
+            from nerf_siren_amd import SemanticNeRF, SirenField
+            sm = SemanticNeRF()
+            sm.load_state_dict({k: torch.from_numpy(v) for k, v in synth.siren_params(seed).items()})
+            m = SirenField(sm, torch.from_numpy(synth.hash_normal((1, 2304), 10 + seed)),
+                           torch.from_numpy(synth.hash_normal((1, 2304), 20 + seed)))
+        else:
+            m = NeRF()
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
         ms.append(m.to(dev))
     emb = [Embedding(3, 10), Embedding(3, 4)]
     rays_np, val_np = synth.psnr_rays(g)
@@ -835,7 +842,7 @@ def _psnr_protocol(g, dev, impl):
         opt = FusedAdam(ms, lr=float(g["cfg_lr"]), eps=1e-8)
         loss_fn = FusedMSELoss(unit_grad=True)
     else:
-        opt = torch.optim.Adam([p for m in ms for p in m.parameters()], lr=float(g["cfg_lr"]), eps=1e-8)
+        opt = torch.optim.Adam([p for m in ms for p in m.param_list()], lr=float(g["cfg_lr"]), eps=1e-8)
         loss_fn = None
     sched = None
     if "cfg_lr_milestones" in g:                            # MultiStepLR, utils/__init__.py:33-50
@@ -881,6 +888,21 @@ def test_psnr_parity(golden, dev, impl):
     print(impl, "psnr hip", np.round(psnr, 3), "reference", np.round(ref, 3))
     assert len(psnr) == len(ref)
     assert abs(psnr[0] - ref[0]) < 0.01                     # untrained: identical models
+    assert np.abs(np.array(psnr) - ref).max() < 0.1, (psnr, ref)
+
+
+@pytest.mark.parametrize("impl", ["torch", "fused"])
+def test_psnr_parity_siren(golden, dev, impl):
+    """The same protocol with the FiLM-SIREN field as the student (g15s: the reference's SemanticNeRF trained by the
+    reference's render_rays + torch autograd on CPU, tools/make_psnr_golden.py --siren): 240 Adam steps through the HIP
+    forward-with-save, dX chain and dW kernels; validation PSNR within 0.1 dB at every evaluation."""
+    g = golden("g15s_psnr_siren")
+    psnr = _psnr_protocol(g, dev, impl, field="siren")
+    ref = g["psnr"]
+    print(impl, "siren psnr hip", np.round(psnr, 3), "reference", np.round(ref, 3))
+    assert len(psnr) == len(ref)
+    assert abs(psnr[0] - ref[0]) < 0.01                     # untrained: identical fields
+    assert ref[-1] > ref[0] + 3.0                           # the reference really learned something
     assert np.abs(np.array(psnr) - ref).max() < 0.1, (psnr, ref)
 
 

@@ -73,6 +73,23 @@ class AnalyticScene(torch.nn.Module):
         return sigma if sigma_only else torch.cat([rgb.clamp(0, 1), sigma], -1)
 
 
+class RefSirenField(torch.nn.Module):
+    """--siren: the reference's SemanticNeRF (models/nerf.py:157-216) behind the interface the reference's render_rays
+    expects of a field -- forward(x, sigma_only) on the embedded input, whose first three xyz / dir channels are the raw
+    xyz / direction (Embedding keeps the input, nerf.py:35).  One conditioning row for all points.  The same adapter the
+    product ships as nerf_siren_amd.SirenField."""
+
+    def __init__(self, m, freq, phase):
+        super().__init__()
+        self.m, self.freq, self.phase = m, torch.from_numpy(freq.copy()), torch.from_numpy(phase.copy())
+
+    def forward(self, x, sigma_only=False):
+        xyz = x[None, :, :3]
+        dirs = torch.zeros_like(xyz) if sigma_only else x[None, :, 63:66]
+        out = self.m.forward_with_frequencies_phase_shifts(xyz, self.freq, self.phase, dirs)[0]      # [rgb, sigma]
+        return out[:, 3:] if sigma_only else out
+
+
 step_rng = synth.psnr_step_rng            # shared with tests/test_gpu_parity.py::test_psnr_parity
 batch_indices = synth.psnr_batch_indices
 
@@ -123,7 +140,18 @@ def main():
     tgt, val_tgt = render(teacher, rays, True), render(teacher, val_rays, True)
     print("teacher rendered", tgt.shape, "mean", tgt.mean(0), "std", tgt.std(0))
 
-    student = [model(synth.nerf_params(11, structured=False)), model(synth.nerf_params(12, structured=False))]
+    siren = "--siren" in sys.argv
+    if siren:
+        import models.nerf as MN
+        MN.np = np                      # nerf.py:131 uses np without importing it
+        c = dict(c, lr=5e-5)
+        student = []
+        for seed in (11, 12):
+            sm = MN.SemanticNeRF()
+            sm.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.siren_params(seed).items()})
+            student.append(RefSirenField(sm, synth.hash_normal((1, 2304), 10 + seed), synth.hash_normal((1, 2304), 20 + seed)))
+    else:
+        student = [model(synth.nerf_params(11, structured=False)), model(synth.nerf_params(12, structured=False))]
     opt = torch.optim.Adam([p for m in student for p in m.parameters()], lr=c["lr"], eps=1e-8)
     sched = (torch.optim.lr_scheduler.MultiStepLR(opt, milestones=c["lr_milestones"], gamma=c["lr_gamma"])
              if "lr_milestones" in c else None)
@@ -158,7 +186,7 @@ def main():
                             psnr=np.array(psnr, np.float32), losses=np.array(losses, np.float32),
                             **{"cfg_" + k: v for k, v in c.items()})
     else:
-        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g15_psnr.npz"), rays=rays, target=tgt, val_rays=val_rays,
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g15s_psnr_siren.npz" if siren else "g15_psnr.npz"), rays=rays, target=tgt, val_rays=val_rays,
                             val_target=val_tgt, psnr=np.array(psnr, np.float32), losses=np.array(losses, np.float32),
                             **{"cfg_" + k: v for k, v in c.items()})
     print("psnr", psnr)
