@@ -1531,6 +1531,44 @@ def test_rccl_backend_reducer_on_one_rank(dev, overlap):
     assert np.abs(plain).max() > 0 and np.array_equal(plain, reduced)
 
 
+# --------------------------------------------------------------------------- every point is computed alone
+@pytest.mark.parametrize("n_per_ray", [64, 128])
+def test_field_kernels_do_not_depend_on_batch_size_or_repetition(dev, ops, models, siren, n_per_ray):
+    """A size-independent property of the field kernels: a point's output depends on nothing but the point, so the first
+    rays of a 1024-ray launch must be BIT-identical to a 37- or 128-ray launch of those rays (different grid sizes,
+    different occupancy, a ragged last wave), and a launch repeated must repeat -- for every kernel variant (NeRF / FiLM-SIREN,
+    exact fp32 / split-bf16, sigma-only / full, inference / forward-with-save).  This is the test that would have caught the
+    stale-operand hazard of csrc/bf16x3_core.h (load-dependent garbage in one split-bf16 instance)."""
+    _, ms = models
+    _, sm = siren
+    nerf = ms[1]
+    freq, phase = T(synth.hash_normal((1, 2304), 311), dev), T(synth.hash_normal((1, 2304), 312), dev)
+    N = 1024
+    rays = T(synth.blender_rays(N, 91), dev)
+    z = T(2.0 + 4.0 * synth.hash_uniform((N, n_per_ray), 92), dev)
+    variants = {
+        "nerf": lambda r, zz, n: ops.nerf_forward_rays(nerf.packed(), r, zz),
+        "nerf sigma": lambda r, zz, n: ops.nerf_forward_rays(nerf.packed(), r, zz, sigma_only=True),
+        "nerf save": lambda r, zz, n: ops.nerf_forward_rays(nerf.packed(), r, zz, save=True)[0],
+        "nerf bf16x3": lambda r, zz, n: ops.nerf_forward_rays_fast(nerf.packed(), nerf.packed_fast(), r, zz),
+        "nerf bf16x3 sigma": lambda r, zz, n: ops.nerf_forward_rays_fast(nerf.packed(), nerf.packed_fast(), r, zz, sigma_only=True),
+        "nerf bf16x3 save": lambda r, zz, n: ops.nerf_forward_rays_fast(nerf.packed(), nerf.packed_fast(), r, zz, save=True)[0],
+        "siren": lambda r, zz, n: ops.siren_forward_rays(sm.packed(), r, zz, freq, phase, n),
+        "siren sigma": lambda r, zz, n: ops.siren_forward_rays(sm.packed(), r, zz, freq, phase, n, sigma_only=True),
+        "siren save": lambda r, zz, n: ops.siren_forward_rays_train(sm.packed(), r, zz, freq, phase, n)[0],
+        "siren bf16x3": lambda r, zz, n: ops.siren_forward_rays_fast(sm.packed(), sm.packed_fast(), r, zz, freq, phase, n),
+        "siren bf16x3 sigma": lambda r, zz, n: ops.siren_forward_rays_fast(sm.packed(), sm.packed_fast(), r, zz, freq, phase, n,
+                                                                      sigma_only=True),
+    }
+    for name, fn in variants.items():
+        full = fn(rays, z, N)
+        assert bool(torch.isfinite(full).all()), name
+        assert torch.equal(fn(rays, z, N), full), name + ": a repeated launch differs"
+        for n in (37, 128):
+            part = fn(rays[:n].contiguous(), z[:n].contiguous(), n)
+            assert torch.equal(part, full[:n * n_per_ray]), f"{name}: {n} rays alone differ from the same rays in a {N}-ray launch"
+
+
 # --------------------------------------------------------------------------- f1 / f3 against the reference's own outputs
 def test_ray_generation_vs_reference_fixture(golden, ops, dev):
     """The HIP ray-generation kernels against datasets/ray_utils.py:5-93 itself (fixture g20, generated by running the
