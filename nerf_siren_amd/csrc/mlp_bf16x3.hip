@@ -126,11 +126,18 @@ nerf_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__res
             float *dst = S.tile + (row0 + 32 * kb + 8 * (r >> 2) + 4 * (S.lane >> 5) + (r & 3)) * 32 + (S.lane & 31);
             __builtin_nontemporal_store(x0, dst);
             __builtin_nontemporal_store(x1, dst + 32);
+#ifdef NERFMI_EXP_MASK_CHAIN
             unsigned one;
             asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(x0));
             asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(mk[kb >> 1]) : "v"(one), "s"(16 * (kb & 1) + r));
             asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(x1));
             asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(mk[kb >> 1]) : "v"(one), "s"(16 * (kb & 1) + r + 1));
+#else
+            unsigned b0, b1;                             // one update of the mask word per pair (mlp_core.h mask_or)
+            asm("v_min_u32 %0, 1, %1" : "=v"(b0) : "v"(x0));
+            asm("v_min_u32 %0, 1, %1" : "=v"(b1) : "v"(x1));
+            mk[kb >> 1] |= ((b1 << 1) | b0) << (16 * (kb & 1) + r);
+#endif
         };
     };
     auto save_raw = [&](int row0) {                      // no activation: values only

@@ -271,6 +271,7 @@ __device__ __forceinline__ void mask_or(unsigned (&mk)[4], int jb, int q, const 
     // out because the compiler expands the C form into compare + select + or.  (Take the element into a
     // scalar first: __builtin_bit_cast applied to a vector element expression is miscompiled by this hipcc.)
     const int sh = 16 * (jb & 1) + 4 * q;
+#ifdef NERFMI_EXP_MASK_CHAIN
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const float v = c[t];
@@ -278,6 +279,19 @@ __device__ __forceinline__ void mask_or(unsigned (&mk)[4], int jb, int q, const 
         asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(v));
         asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(mk[jb >> 1]) : "v"(one), "s"(sh + t));
     }
+#else
+    // the four bits are combined as a TREE and join the mask word once per slice: a vector instruction that consumes the
+    // previous one's result issues after 8 cycles, an independent one after 4 (tools/ubench/mfma_valu.hip), so four
+    // v_lshl_or_b32 chained through the mask word cost twice their issue slots
+    unsigned b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float v = c[t];
+        asm("v_min_u32 %0, 1, %1" : "=v"(b[t]) : "v"(v));
+    }
+    const unsigned lo = (b[1] << 1) | b[0], hi = (b[3] << 1) | b[2];
+    mk[jb >> 1] |= ((hi << 2) | lo) << sh;
+#endif
 }
 __device__ __forceinline__ bool mask_bit(const unsigned (&mk)[4], int jb, int q, int t) {
     return (mk[jb >> 1] >> (16 * (jb & 1) + 4 * q + t)) & 1u;

@@ -19,6 +19,8 @@ __global__ void __launch_bounds__(256) k(float *out, unsigned long long *ts, int
     f32x4 ld[4] = {av, av, av, av};
     const unsigned laddr = (threadIdx.x & 63) * 16;
     const float *gaddr = out + blockIdx.x * 256 + threadIdx.x;
+    float *sdst = out + 256 * 256 * 2 + blockIdx.x * 64;            // wave-uniform: lives in an SGPR pair
+    unsigned mkw = 0;
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -43,6 +45,26 @@ __global__ void __launch_bounds__(256) k(float *out, unsigned long long *ts, int
                 if (KIND == 15) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(y) : "v"(b), "v"(a));
                 if (KIND == 16) asm volatile("v_accvgpr_read_b32 %0, a5" : "=v"(y));
                 if (KIND == 17) asm volatile("v_max_i32 %0, 0, %0" : "+v"(y));
+                // ReLU sign masks as LANE masks: one compare into an SGPR pair (18), plus a scalar store of the pair (19)
+                if (KIND == 18 || KIND == 19) asm volatile("v_cmp_gt_f32_e64 s[20:21], %0, %1" : : "v"(y), "v"(b) : "s20", "s21");
+                if (KIND == 19) asm volatile("s_store_dwordx2 s[20:21], %0, 0x0" : : "s"(sdst) : "memory");
+                // ... against today's form: v_min_u32 + v_lshl_or_b32 into a packed word (20)
+                if (KIND == 21) asm volatile("v_min_u32 %0, 1, %0" : "+v"(y));
+                if (KIND == 22) asm volatile("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(mkw) : "v"(y), "s"(u));
+                if (KIND == 23) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(mkw) : "v"(y));
+                if (KIND == 24) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(mkw) : "v"(y));
+                if (KIND == 25) asm volatile("v_sub_u32 %0, 0, %0" : "+v"(y));
+                if (KIND == 26) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(mkw) : "v"(y));
+                if (KIND == 27) {      // candidate: integer negate (MSB = value != +0) + alignbit
+                    unsigned t;
+                    asm volatile("v_sub_u32 %0, 0, %1" : "=v"(t) : "v"(y));
+                    asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(mkw) : "v"(t));
+                }
+                if (KIND == 20) {
+                    unsigned one;
+                    asm volatile("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(y));
+                    asm volatile("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(mkw) : "v"(one), "s"(u));
+                }
                 if (KIND == 7) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[(u * V + v) % 4]) : "v"(laddr));
                 if (KIND == 8) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[(u * V + v) % 4]) : "v"(gaddr));
                 if (KIND == 9) asm volatile("ds_write_b128 %0, %1" : : "v"(laddr), "v"(ld[0]));
@@ -55,7 +77,9 @@ __global__ void __launch_bounds__(256) k(float *out, unsigned long long *ts, int
     unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+    if (KIND == 19) asm volatile("s_dcache_wb\n s_waitcnt lgkmcnt(0)");
     for (int r = 0; r < 16; ++r) s += c[r] + c2[r] + x[r] + ld[r & 3][r >> 2];
+    s += (float)mkw;
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) ts[0] = t1 - t0;
 }
@@ -91,6 +115,18 @@ int main() {
     run<8, 1, 3>("global_load_x4"); run<8, 2, 3>("global_load_x4");
     run<9, 1, 3>("ds_write_b128"); run<9, 2, 3>("ds_write_b128");
     run<10, 1, 3>("global_store_dw"); run<10, 2, 3>("global_store_dw");
+    printf("fp32 MFMA chain + ReLU-mask forms (per value): lane mask by v_cmp into SGPRs, the same + s_store_dwordx2, today's v_min+v_lshl_or:\n");
+    run<18, 2>("v_cmp->sgpr"); run<18, 4>("v_cmp->sgpr"); run<18, 8>("v_cmp->sgpr");
+    run<19, 2>("v_cmp+s_store"); run<19, 4>("v_cmp+s_store"); run<19, 8>("v_cmp+s_store");
+    run<20, 2>("v_min+v_lshl_or"); run<20, 4>("v_min+v_lshl_or"); run<20, 8>("v_min+v_lshl_or");
+    printf("single instructions after an fp32 MFMA (V = 4, 8):\n");
+    run<21, 4>("v_min_u32"); run<21, 8>("v_min_u32");
+    run<22, 4>("v_lshl_or sgpr"); run<22, 8>("v_lshl_or sgpr");
+    run<23, 4>("v_lshl_or const"); run<23, 8>("v_lshl_or const");
+    run<24, 4>("v_alignbit"); run<24, 8>("v_alignbit");
+    run<25, 4>("v_sub_u32"); run<25, 8>("v_sub_u32");
+    run<26, 4>("v_lshl_add_u32"); run<26, 8>("v_lshl_add_u32");
+    run<27, 2>("v_sub+v_alignbit"); run<27, 4>("v_sub+v_alignbit"); run<27, 8>("v_sub+v_alignbit");
     printf("bf16 32x32x16 MFMA, one dependent chain:\n");
     run<0, 0, 3>("v_fma_f32"); run<0, 1, 3>("v_fma_f32"); run<0, 2, 3>("v_fma_f32"); run<0, 4, 3>("v_fma_f32"); run<0, 6, 3>("v_fma_f32"); run<0, 8, 3>("v_fma_f32"); run<0, 12, 3>("v_fma_f32");
     printf("bf16 32x32x16 MFMA, two chains:\n");
