@@ -40,11 +40,12 @@ __device__ __forceinline__ float sin_cw(float x) {
 }
 
 // sin(x) by reduction modulo PI: x = j*pi + r, |r| <= pi/2, sin x = (-1)^j sin r, and cos x = (-1)^j cos r with
-// cos r >= 0 -- so ONE odd polynomial (degree 11, max abs error 1.2e-7 = 2 ulp of 1 for |x| <= 300, mean 1.6e-8;
-// fitted in tools/fit_sin.py) serves every quadrant and the parity of j is at once the sign of the sine's flip and the
-// SIGN OF THE COSINE, which is all the FiLM-SIREN backward needs beside the saved sine.  j is rounded with the
-// 1.5 * 2^23 magic constant, so its parity is bit 0 of `jbits`.  13 VALU instructions against ~20 for sincos_cw -- the
-// 2304 sines per point are the FiLM-SIREN field's whole vector load.
+// cos r >= 0 -- so ONE odd polynomial (degree 9: max abs error 1.4e-7 = 2.3 ulp of 1 for |x| <= 300, mean 1.6e-8,
+// fitted in tools/fit_sin.py; the degree-11 fit is no better in fp32 -- 2.0 ulp, the rounding of the last steps
+// dominates -- and costs one more fma on each of the 2304 sines per point) serves every quadrant and the parity of j
+// is at once the sign of the sine's flip and the SIGN OF THE COSINE, which is all the FiLM-SIREN backward needs
+// beside the saved sine.  j is rounded with the 1.5 * 2^23 magic constant, so its parity is bit 0 of `jbits`.
+// 12 VALU instructions against ~20 for sincos_cw -- the sines are the FiLM-SIREN field's whole vector load.
 __device__ __forceinline__ float sin_pi(float x, unsigned &jbits) {
     const float MAGIC = 12582912.0f;
     const float jm = __builtin_fmaf(x, 0.31830988618379067f, MAGIC);
@@ -52,10 +53,16 @@ __device__ __forceinline__ float sin_pi(float x, unsigned &jbits) {
     float r = __builtin_fmaf(-j, 3.14159274101257324f, x);            // pi hi (fp32)
     r = __builtin_fmaf(-j, -8.74227765734758577e-8f, r);               // pi lo
     const float r2 = r * r;
+#ifdef NERFMI_EXP_SIN11
     float p = __builtin_fmaf(-2.3846691732387626e-08f, r2, 2.752261934801936e-06f);
     p = __builtin_fmaf(p, r2, -0.00019840804452542216f);
     p = __builtin_fmaf(p, r2, 0.008333330042660236f);
     p = __builtin_fmaf(p, r2, -0.1666666716337204f);
+#else
+    float p = __builtin_fmaf(2.600054585855105e-06f, r2, -0.00019806614727713168f);
+    p = __builtin_fmaf(p, r2, 0.008333017118275166f);
+    p = __builtin_fmaf(p, r2, -0.16666656732559204f);
+#endif
     const float s = __builtin_fmaf(r * r2, p, r);
     jbits = __float_as_uint(jm);
     return __uint_as_float(__float_as_uint(s) ^ (jbits << 31));
