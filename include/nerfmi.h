@@ -151,7 +151,7 @@ int nerfmi_siren_forward_rays(const float *packed, const float *rays, const floa
                               int sigma_only, float *out, nerfmi_stream_t stream);
 
 /* Training path of the FiLM-SIREN field (autograd of models/nerf.py:142-151, :201-216 w.r.t. the 22 parameters; the
- * inputs and the conditioning rows carry no gradient here).  The *_train forwards also write `saved`
+ * inputs carry no gradient; the conditioning rows: nerfmi_siren_backward_cond).  The *_train forwards also write `saved`
  * (nerfmi_siren_saved_floats(n_points) floats: per 32-point tile the layer inputs and one sign bit of cos per unit);
  * nerfmi_siren_backward turns grad_out (n_points,4) = [d rgb, d sigma] into the 22 gradients (written, not
  * accumulated; bit-reproducible: fixed-order slab reduction, no float atomics).  grad_params: HOST array of 22 DEVICE
@@ -167,6 +167,14 @@ int nerfmi_siren_forward_points_train(const float *packed, const float *points, 
 int nerfmi_siren_backward(const float *packed, const float *saved, const float *grad_out, const float *frequencies,
                           int64_t n_points, int64_t points_per_cond, float *const *grad_params, float *workspace,
                           nerfmi_stream_t stream);
+/* The same backward for a launch that shares ONE conditioning row, with the gradients of that row as well
+ * (models/nerf.py:147-151, :201-216 are differentiable in `frequencies` / `phase_shifts`, which the reference's mapping
+ * network -- nerf.py:185 -- would produce): grad_frequencies, grad_phase_shifts (9*256 floats each, written).  They come out
+ * of the dW slab reduction (one dot product per unit), not out of a second pass over the activations.  Several
+ * conditioning rows: one forward_*_train + one call per row. */
+int nerfmi_siren_backward_cond(const float *packed, const float *saved, const float *grad_out, const float *frequencies,
+                               int64_t n_points, float *const *grad_params, float *grad_frequencies,
+                               float *grad_phase_shifts, float *workspace, nerfmi_stream_t stream);
 
 /* OPT-IN split-bf16 math for the FiLM-SIREN field (see nerfmi_nerf_forward_rays_fast): `fast`
  * (nerfmi_siren_fast_bytes() bytes) is derived from the SIREN `packed` blob by nerfmi_siren_pack_fast. */

@@ -50,6 +50,7 @@ SIGNATURES = {
     "nerfmi_siren_forward_rays_train": (_i, [_f, _f, _f, _f, _f, _i, _i, _i64, _f, _f, _f]),
     "nerfmi_siren_forward_points_train": (_i, [_f, _f, _f, _f, _f, _i64, _i64, _f, _f, _f]),
     "nerfmi_siren_backward": (_i, [_f, _f, _f, _f, _i64, _i64, C.POINTER(C.c_void_p), _f, _f]),
+    "nerfmi_siren_backward_cond": (_i, [_f, _f, _f, _f, _i64, C.POINTER(C.c_void_p), _f, _f, _f, _f]),
     "nerfmi_eg3d_pack_planes": (_i, [_f, _i, _i, _i, _i, _f, _f]),
     "nerfmi_eg3d_decoder_floats": (C.c_size_t, []),
     "nerfmi_eg3d_pack_decoder": (_i, [_f, _f, _f, _f, _fl, _f, _f]),

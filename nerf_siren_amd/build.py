@@ -41,11 +41,17 @@ def _deps(src: str, seen=None) -> set:
     return seen
 
 
-def _stale(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=()) -> str:
+    """sha256 over the CONTENT of `paths` (sorted) and the strings in `extra`: what "up to date" is judged by, so that a
+    fresh checkout (all mtimes = now) and the tree the library was built in agree."""
+    h = hashlib.sha256()
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def _cflags():
@@ -54,8 +60,8 @@ def _cflags():
 
 
 def _objdir():
-    # objects are kept between builds (one per translation unit, rebuilt when the unit or a header it includes changed);
-    # a different flag set gets its own directory so experiment builds never mix with the product objects
+    # objects are kept between builds (one per translation unit, rebuilt when the CONTENT of the unit or of a header it
+    # includes changed); a different flag set gets its own directory so experiment builds never mix with the product objects
     tag = hashlib.sha1(" ".join(_cflags()).encode()).hexdigest()[:10]
     return os.path.join(HERE, "lib", "obj-" + tag)
 
@@ -66,46 +72,91 @@ def _jobs():
     missing = [s for s in srcs if not os.path.exists(s)]
     if missing:
         raise RuntimeError(f"missing sources: {missing}")
-    me = os.path.abspath(__file__)
-    return [(src, os.path.join(_objdir(), os.path.basename(src) + ".o"), _deps(src) | {me}) for src in srcs]
+    out = []
+    for src in srcs:
+        obj = os.path.join(_objdir(), os.path.basename(src) + ".o")
+        out.append((src, obj, _digest(_deps(src), _cflags())))
+    return out
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _obj_current(obj, digest) -> bool:
+    return os.path.exists(obj) and _read(obj + ".sha256") == digest
+
+
+def _lib_digest(jobs) -> str:
+    return hashlib.sha256("\n".join(d for _, _, d in jobs).encode()).hexdigest()
 
 
 def needs_build() -> bool:
     jobs = _jobs()
-    return any(_stale(obj, deps) for _, obj, deps in jobs) or _stale(LIB, [obj for _, obj, _ in jobs if os.path.exists(obj)])
+    return not (os.path.exists(LIB) and _read(LIB + ".sha256") == _lib_digest(jobs))
+
+
+# what the last build() call in this process did: {"compiled": [...], "reused": [...], "linked": bool}
+LAST_BUILD = {"compiled": [], "reused": [], "linked": False}
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every translation unit whose content digest (sources + quoted headers + flags) differs from the one its
+    object was built from, link to a temporary name once ALL objects exist, then move the library into place."""
+    jobs = _jobs()
+    LAST_BUILD.update(compiled=[], reused=[], linked=False)
     if not force and not needs_build():
+        LAST_BUILD["reused"] = [os.path.basename(s) for s, _, _ in jobs]
+        if verbose:
+            print(f"libnerfmi.so is up to date (content digest of {len(jobs)} translation units matches): compiled 0, "
+                  f"reused {len(jobs)}", flush=True)
         return LIB
     os.makedirs(_objdir(), exist_ok=True)
-    jobs = [(src, obj, [hipcc()] + _cflags() + ["-c", src, "-o", obj]) for src, obj, deps in _jobs()
-            if force or _stale(obj, deps)]
+    todo = [(src, obj, dig, [hipcc()] + _cflags() + ["-c", src, "-o", obj]) for src, obj, dig in jobs
+            if force or not _obj_current(obj, dig)]
+    LAST_BUILD["reused"] = [os.path.basename(s) for s, o, d in jobs if not any(s == t[0] for t in todo)]
 
     def run(job):
-        src, obj, cmd = job
+        src, obj, dig, cmd = job
         if verbose:
             print(" ".join(cmd), flush=True)
+        for stale in (obj, obj + ".sha256"):
+            if os.path.exists(stale):
+                os.remove(stale)
         r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0 and os.path.exists(obj):
+        if r.returncode == 0:
+            with open(obj + ".sha256", "w") as f:
+                f.write(dig)
+        elif os.path.exists(obj):
             os.remove(obj)
         return src, r
 
     # the fully unrolled MLP kernels take minutes each: compile the translation units side by side
     from concurrent.futures import ThreadPoolExecutor
-    if jobs:
-        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
-            for src, r in ex.map(run, jobs):
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as ex:
+            for src, r in ex.map(run, todo):
                 if r.returncode != 0:
                     raise RuntimeError(f"hipcc failed on {src}:\n" + r.stdout + r.stderr)
+                LAST_BUILD["compiled"].append(os.path.basename(src))
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for _, obj, _ in _jobs()] + ["-o", LIB + ".tmp"]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for _, obj, _ in jobs] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
     os.replace(LIB + ".tmp", LIB)
+    with open(LIB + ".sha256", "w") as f:
+        f.write(_lib_digest(jobs))
+    LAST_BUILD["linked"] = True
+    if verbose:
+        print(f"compiled {len(LAST_BUILD['compiled'])} translation unit(s) {LAST_BUILD['compiled']}, reused "
+              f"{len(LAST_BUILD['reused'])}, linked {os.path.basename(LIB)}", flush=True)
     return LIB
 
 

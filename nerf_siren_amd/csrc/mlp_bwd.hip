@@ -481,11 +481,17 @@ static DwPlan make_plan(int64_t ld, bool fast = false) {
     // 38.2 / 18.5 / 25.5 / 8.4 / 8.5 / 12.6 M cycles per task at 4096 tiles); the tiny tasks 3..5 stay on the fp32 path
     static const int base_fast[6] = {24, 12, 18, 6, 6, 10};
     const int *base = fast ? base_fast : base_fp32;
+#ifdef NERFMI_TIMING
+    // experiment builds only (tools/exp_dw_timing.py): "c0,c1,c2,c3,c4,c5", validated -- the product never reads the environment
     int base_env[6];
-    if (const char *e = getenv("NERFMI_DW_CHUNKS")) {       // experiments (tools/exp_dw_timing.py): "c0,c1,c2,c3,c4,c5"
-        if (sscanf(e, "%d,%d,%d,%d,%d,%d", base_env, base_env + 1, base_env + 2, base_env + 3, base_env + 4, base_env + 5) == 6)
-            base = base_env;
+    if (const char *e = getenv("NERFMI_DW_CHUNKS")) {
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d", base_env, base_env + 1, base_env + 2, base_env + 3, base_env + 4, base_env + 5) == 6) {
+            bool ok = true;
+            for (int i = 0; i < 6; ++i) ok = ok && base_env[i] >= 1 && base_env[i] <= 64;
+            if (ok) base = base_env;
+        }
     }
+#endif
     const int64_t tiles = ld / 32;
     int wg = 0, off = 0;
     for (int i = 0; i < n; ++i) {

@@ -106,17 +106,24 @@ siren_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__re
         const int r = 2 * pr;
         const int u = 256 * layer + 32 * kb + 8 * (r >> 2) + (r & 3);
         const float2 f = *reinterpret_cast<const float2 *>(fq + u), s = *reinterpret_cast<const float2 *>(ph + u);
-        // sin_pi as in the fp32 kernels.  (Round 2 first saw scattered garbage / NaN with it here and fell back to sin_cw;
-        // the cause was not the sine but an asm bf16 conversion in split_pair scheduled right in front of its MFMA --
-        // bf16x3_core.h, tools/hazard_scan.py -- which this instruction mix happened to expose.)
-#ifndef NERFMI_EXP_FAST_SINCW
-        unsigned jb0, jb1;
-        x0 = sin_pi(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.x, 15.0f), 30.0f), x0), s.x), jb0);
-        x1 = sin_pi(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.y, 15.0f), 30.0f), x1), s.y), jb1);
-#else
-        x0 = sin_cw(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.x, 15.0f), 30.0f), x0), s.x));
-        x1 = sin_cw(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.y, 15.0f), 30.0f), x1), s.y));
-#endif
+        // the hardware sine on pre-divided FiLM constants, as in the fp32 kernels (siren_core.h): ~3 issue slots per value
+        // where rounds 1-2 spent 13 on the polynomial -- this hook runs between the consuming layer's XDL MFMAs, which
+        // hide about five vector instructions each
+        // (written as single-value asm: left to the compiler these become v_pk_fma_f32 / v_pk_mul_f32, and packed-fp32
+        // instructions do not overlap with the bf16 MFMAs, bf16x3_core.h split_pair; their results feed v_sin_f32, never an
+        // MFMA operand, so the inline-asm hazard of bf16x3_core.h does not arise)
+        float fr0, fr1, p0, p1, t0, t1;
+        const float k15 = 15.0f, k30 = 30.0f, kinv = INV_2PI;
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(fr0) : "v"(f.x), "v"(k15), "v"(k30));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(fr1) : "v"(f.y), "v"(k15), "v"(k30));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(fr0) : "v"(fr0), "v"(kinv));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(fr1) : "v"(fr1), "v"(kinv));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(p0) : "v"(s.x), "v"(kinv));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(s.y), "v"(kinv));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(fr0), "v"(x0), "v"(p0));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(fr1), "v"(x1), "v"(p1));
+        x0 = __builtin_amdgcn_sinf(t0);
+        x1 = __builtin_amdgcn_sinf(t1);
     };
     auto film_hook = [&film](int layer) {
         return [&film, layer](int kb, int pr, float &x0, float &x1) { film(layer, kb, pr, x0, x1); };

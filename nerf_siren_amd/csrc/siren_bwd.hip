@@ -10,7 +10,15 @@
 //     with the sign from the forward's bitmask: nothing but the sines is re-read.  Every dZ_l goes to the workspace as
 //     a tile-major image.
 //  2. dW_l = dZ_l^T . X_l: the NeRF dW GEMM (dw_core.h) on a 12-task plan of exactly 256 workgroups.
-//  3. deterministic slab reduction (dw_core.h): bit-reproducible gradients.
+//  3. deterministic slab reduction (siren_dw_reduce_kernel below): bit-reproducible gradients -- and, when the launch
+//     shares ONE conditioning row, the gradients of that row (frequencies, phase_shifts: nerf.py:147-151, :201-216 are
+//     differentiable in them) from the same slabs.  With  arg = fr (W h + b) + ph,  fr = 15 f + 30,  G = dH cos(arg):
+//         dZ = fr G,   dW = fr (G^T X),   db = fr sum_p G,   d ph = sum_p G,
+//         d f = 15 sum_p G (W h + b) = 15 (<W_j, (G^T X)_j> + b_j sum_p G_j)
+//     -- every term is a row operation on the UNSCALED slabs G^T X.  So in that mode the chain kernel writes G (not dZ) to
+//     the workspace (it still hands dZ = fr G to the next layer's MFMAs: same instruction count), the reduction scales the
+//     rows by fr, and the conditioning gradients cost one dot product per unit: no division by fr (fr = 0 is legal), no
+//     second pass over the activations.
 #include <stdlib.h>
 
 #include "dw_core.h"
@@ -19,7 +27,7 @@
 namespace nerfmi {
 
 // workspace row map (tile-major images written by the chain kernel)
-constexpr int SW_DZ = 0;                   // 9 x 256: dZ of network.0..7, then color_layer_sine
+constexpr int SW_DZ = 0;                   // 9 x 256: dZ of network.0..7, then color_layer_sine (G = dZ / fr in one-row launches)
 constexpr int SW_DRGB = 9 * 256;           // 3 (+1 pad): d rgb pre-sigmoid
 constexpr int SW_DSIG = SW_DRGB + 4;       // 1 (+3 pad): d sigma
 constexpr int SW_ROWS = SW_DSIG + 4;
@@ -37,9 +45,11 @@ __device__ __forceinline__ f32x16 load_block(const RowImage &im, int row0) {
 
 // d pre = d h * fr * cos(arg) for the four units of slice q of block jb (layer `layer`):
 // s = saved sines (this lane's 16 of the block), sign bits of the cosines in mk, fr from LDS (COND_LDS) or memory
+// Returns dZ = fr * G (the next layer's MFMA operand); `g` receives what goes to the workspace image: G = dh * cos(arg) when
+// the launch shares one conditioning row (COND_LDS: the reduction scales the rows by fr), dZ otherwise.
 template <bool COND_LDS>
 __device__ __forceinline__ f32x4 film_grad(f32x4 dh, const f32x16 &s, const unsigned (&mk)[4], const float *fq,
-                                           const float *lfr, int layer, int jb, int q) {
+                                           const float *lfr, int layer, int jb, int q, f32x4 &g) {
     f32x4 fr;
     if (COND_LDS) {
         fr = *reinterpret_cast<const f32x4 *>(lfr + 256 * layer + 32 * jb + 8 * q);
@@ -48,16 +58,29 @@ __device__ __forceinline__ f32x4 film_grad(f32x4 dh, const f32x16 &s, const unsi
 #pragma unroll
         for (int t = 0; t < 4; ++t) fr[t] = __fadd_rn(__fmul_rn(f[t], 15.0f), 30.0f);                  // nerf.py:202
     }
+    // Two values per instruction where the ISA has a packed fp32 form (v_pk_fma_f32 / v_pk_mul_f32 issue like their scalar
+    // forms, tools/ubench/pk_valu.hip): cos^2 = 1 - s^2 in one rounding (no worse than the sine's own), the products with
+    // dh and fr.  |cos| by the raw v_sqrt_f32 (1 ulp, two issue slots; sqrtf() is expanded to the correctly rounded
+    // sequence -- scale, refine, classify: ~14 instructions -- and |cos| feeds a product, not a parity check) of |cos^2|
+    // through the free |x| source modifier: a saved sine one ulp above 1 gives cos^2 = -1.2e-7, where the true |cos| is below
+    // 5e-4 either way.  The cosine's sign: bit (sh + t) of the mask word moved to bit 31 and OR-ed in (v_lshlrev + v_and_or).
+    const f32x2 one = {1.0f, 1.0f};
+    f32x2 cs[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float sv = s[4 * q + t];
-        const float c2 = __builtin_fmaf(-sv, sv, 1.0f);         // cos^2 = 1 - s^2, one rounding (no worse than the sine's own)
-        // the raw v_sqrt_f32 (1 ulp): sqrtf() is expanded to the correctly rounded sequence (scale, refine, classify:
-        // ~14 instructions) which tripled this epilogue's vector work -- and |cos| feeds a product, not a parity check
-        const float ca = __builtin_amdgcn_sqrtf(fmaxf(c2, 0.f));
-        // the cosine's sign: bit (sh + t) of the mask word moved to bit 31 and OR-ed in (v_lshlrev + v_and_or)
-        const unsigned sgn = (mk[jb >> 1] << (31 - (16 * (jb & 1) + 4 * q + t))) & 0x80000000u;
-        dh[t] = dh[t] * (fr[t] * __uint_as_float(__float_as_uint(ca) | sgn));
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 sv = {s[4 * q + 2 * h], s[4 * q + 2 * h + 1]};
+        const f32x2 c2 = fma2(-sv, sv, one);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int t = 2 * h + e;
+            const float ca = __builtin_amdgcn_sqrtf(__builtin_fabsf(c2[e]));
+            const unsigned sgn = (mk[jb >> 1] << (31 - (16 * (jb & 1) + 4 * q + t))) & 0x80000000u;
+            cs[h][e] = __uint_as_float(__float_as_uint(ca) | sgn);
+        }
+        const f32x2 gg = f32x2{dh[2 * h], dh[2 * h + 1]} * cs[h];
+        const f32x2 dz = gg * f32x2{fr[2 * h], fr[2 * h + 1]};
+        dh[2 * h] = dz[0]; dh[2 * h + 1] = dz[1];
+        g[2 * h] = COND_LDS ? gg[0] : dz[0]; g[2 * h + 1] = COND_LDS ? gg[1] : dz[1];
     }
     return dh;
 }
@@ -120,12 +143,13 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 dh[t] = __builtin_fmaf(w[2][t], dpre[2], __builtin_fmaf(w[1][t], dpre[1], w[0][t] * dpre[0]));
-            dh = film_grad<COND_LDS>(dh, sv, mk, fq, lfr, 8, b, q);
+            f32x4 g;
+            dh = film_grad<COND_LDS>(dh, sv, mk, fq, lfr, 8, b, q, g);
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[4 * q + t] = dh[t];
+            store_slice(Wk, SW_DZ + 8 * 256 + 32 * b, q, g);
         }
         dzA[b] = v;
-        store_block(Wk, SW_DZ + 8 * 256 + 32 * b, v);
     }
     __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
     const int wid = threadIdx.x >> 6;
@@ -138,8 +162,9 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
                                          const f32x4 w = ldg4(packed + SOFF_W_SIGMA + 32 * jb + 8 * q + 4 * half);
 #pragma unroll
                                          for (int t = 0; t < 4; ++t) c[t] = __builtin_fmaf(w[t], dsig, c[t]);
-                                         c = film_grad<COND_LDS>(c, sv, mk, fq, lfr, 7, jb, q);
-                                         store_slice(Wk, SW_DZ + 7 * 256 + 32 * jb, q, c);
+                                         f32x4 g;
+                                         c = film_grad<COND_LDS>(c, sv, mk, fq, lfr, 7, jb, q, g);
+                                         store_slice(Wk, SW_DZ + 7 * 256 + 32 * jb, q, g);
                                          return c;
                                      }, wlds, ws, wid, lane);
     // network.7 .. network.1: d h_{l-1} = W_l^T dZ_l;  dZ_{l-1} = d h_{l-1} * fr_{l-1} * cos(arg_{l-1})
@@ -148,8 +173,9 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
         layer_mfma_lds<8, 0, 8, 0, false>(packed + SOFF_T7 + (7 - l) * SZ_HID, nullptr, in, nullptr, out_dz,
                                           [&S, l](int jb) { return load_block(S, SS_H + (l - 1) * 256 + 32 * jb); },
                                           [&, l](int jb, int q, f32x4 c, const f32x16 &sv) {
-                                              c = film_grad<COND_LDS>(c, sv, mk, fq, lfr, l - 1, jb, q);
-                                              store_slice(Wk, SW_DZ + (l - 1) * 256 + 32 * jb, q, c);
+                                              f32x4 g;
+                                              c = film_grad<COND_LDS>(c, sv, mk, fq, lfr, l - 1, jb, q, g);
+                                              store_slice(Wk, SW_DZ + (l - 1) * 256 + 32 * jb, q, g);
                                               return c;
                                           }, wlds, ws, wid, lane);
     };
@@ -191,6 +217,75 @@ siren_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__rest
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// 3. slab reduction, one workgroup per (parameter row, layer group): fixed summation order (bit-reproducible), the FiLM
+//    row scale of one-row launches, and the conditioning-row gradients (header of this file).
+//    Layer groups: 0..7 = network.l (task l), 8 = color_layer_sine (tasks 8 + 9: direction and hidden columns),
+//    9 = color_layer_linear (task 10), 10 = final_layer (task 11).
+// ---------------------------------------------------------------------------
+constexpr int SIREN_GROUPS = 11;
+
+// W_g[j][col] read back from the packed forward image (siren_pack_kernel's map inverted)
+__device__ __forceinline__ float packed_weight(const float *__restrict__ packed, int g, int j, int col) {
+    int base, KB, kc;
+    if (g == 0) { base = SOFF_L1; KB = 1; kc = col; }
+    else if (g < 8) { base = SOFF_L2 + (g - 1) * SZ_HID; KB = 8; kc = col; }
+    else { base = SOFF_COLOR; KB = 9; kc = (col < 3) ? col : 32 + (col - 3); }
+    const int jb = j >> 5, kb = kc >> 5, r = kc & 31;
+    const int lane = ((r >> 2) & 1) * 32 + (j & 31);
+    return packed[base + ((jb * KB + kb) * 4 + (r >> 3)) * 256 + lane * 4 + (r & 3)];
+}
+
+__global__ void __launch_bounds__(256)
+siren_dw_reduce_kernel(DwPlan plan, const float *__restrict__ partial, GradPtrs G, const float *__restrict__ packed,
+                       const float *__restrict__ freq, int row_scale, float *__restrict__ d_freq,
+                       float *__restrict__ d_phase) {
+    const int j = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int t_first = (g < 8) ? g : (g == 8 ? 8 : g + 1), n_t = (g == 8) ? 2 : 1;
+    if (j >= plan.t[t_first].a_valid) return;
+    const bool film = g <= 8;
+    const float fr = (film && row_scale) ? __fadd_rn(__fmul_rn(freq[256 * g + j], 15.0f), 30.0f) : 1.0f;   // nerf.py:202
+    float dot = 0.f, sb = 0.f;
+    for (int ti = t_first; ti < t_first + n_t; ++ti) {
+        const DwTask T = plan.t[ti];
+        const int cols = T.KB * 32, slab = T.JB * 32 * (cols + 1);
+        const float *src = partial + T.part_off + j * cols;
+        for (int k = tid; k < cols; k += 256) {
+            float s = 0.f;
+            int c = 0;
+            for (; c + 8 <= T.chunks; c += 8) {           // eight slab loads in flight instead of one HBM round trip per chunk
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(c + u) * slab + k];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; c < T.chunks; ++c) s += src[(int64_t)c * slab + k];
+            if (k < T.b_valid) {
+                G.p[T.param][j * T.in_f + T.out_col0 + k] = fr * s;
+                if (film && d_freq) dot = __builtin_fmaf(packed_weight(packed, g, j, T.out_col0 + k), s, dot);
+            }
+        }
+        if (T.bias_param >= 0) {                          // every thread: same addresses, one broadcast load per chunk
+            const float *bsrc = partial + T.part_off + T.JB * 32 * cols + j;
+            for (int c = 0; c < T.chunks; ++c) sb += bsrc[(int64_t)c * slab];
+            if (tid == 0) G.p[T.bias_param][j] = fr * sb;
+        }
+    }
+    if (!(film && d_freq)) return;
+    // <W_j, (G^T X)_j> over the workgroup in a fixed tree
+    __shared__ float red[4];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, WAVE);
+    if ((tid & 63) == 0) red[tid >> 6] = dot;
+    __syncthreads();
+    if (tid == 0) {
+        const float d = (red[0] + red[1]) + (red[2] + red[3]);
+        d_freq[256 * g + j] = 15.0f * __builtin_fmaf(packed[SOFF_BIAS + 256 * g + j], sb, d);
+        d_phase[256 * g + j] = sb;
+    }
+}
+
 static const int SKIND_JB[3] = {8, 8, 1};
 static const int SKIND_KB[3] = {8, 1, 8};
 
@@ -215,10 +310,15 @@ static DwPlan siren_plan(int64_t ld) {
     // as 64-column tasks they kept 20 workgroups busy multiplying zero padding.
     static const int chunks_default[3] = {29, 6, 6};
     const int *chunks = chunks_default;
+#ifdef NERFMI_TIMING
+    // experiment builds only (tools/exp_siren_dw_timing.py): "c0,c1,c2", validated -- the product never reads the environment
     int chunks_env[3];
-    if (const char *e = getenv("NERFMI_SIREN_DW_CHUNKS")) {     // experiments (tools/exp_siren_dw_timing.py): "c0,c1,c2"
-        if (sscanf(e, "%d,%d,%d", chunks_env, chunks_env + 1, chunks_env + 2) == 3) chunks = chunks_env;
+    if (const char *e = getenv("NERFMI_SIREN_DW_CHUNKS")) {
+        if (sscanf(e, "%d,%d,%d", chunks_env, chunks_env + 1, chunks_env + 2) == 3 && chunks_env[0] >= 1 && chunks_env[1] >= 1 &&
+            chunks_env[2] >= 1 && 8 * chunks_env[0] + 2 * chunks_env[1] + 2 * chunks_env[2] <= 512)
+            chunks = chunks_env;
     }
+#endif
     dw_finish_plan(P, SKIND_JB, SKIND_KB, chunks, ld);
     return P;
 }
@@ -275,16 +375,24 @@ int nerfmi_siren_forward_points_train(const float *packed, const float *points, 
     return check_launch("siren_forward_points_train");
 }
 
-int nerfmi_siren_backward(const float *packed, const float *saved, const float *grad_out, const float *frequencies,
-                          int64_t n_points, int64_t points_per_cond, float *const *grad_params, float *workspace,
-                          nerfmi_stream_t stream) {
-    NERFMI_REQUIRE(n_points >= 1 && points_per_cond >= 1, "siren_backward: bad sizes");
-    NERFMI_REQUIRE(packed && saved && grad_out && frequencies && grad_params && workspace, "siren_backward: null pointer");
+static int siren_backward_impl(const char *who, const float *packed, const float *saved, const float *grad_out,
+                               const float *frequencies, int64_t n_points, int64_t points_per_cond,
+                               float *const *grad_params, float *grad_frequencies, float *grad_phase_shifts,
+                               float *workspace, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(n_points >= 1 && points_per_cond >= 1, "%s: bad sizes", who);
+    NERFMI_REQUIRE(packed && saved && grad_out && frequencies && grad_params && workspace, "%s: null pointer", who);
+    const bool one_cond = points_per_cond >= n_points;
+    const bool want_cond = grad_frequencies || grad_phase_shifts;
+    NERFMI_REQUIRE(!want_cond || (grad_frequencies && grad_phase_shifts),
+                   "%s: grad_frequencies and grad_phase_shifts come together", who);
+    NERFMI_REQUIRE(!want_cond || one_cond,
+                   "%s: conditioning gradients need a launch that shares one conditioning row (points_per_cond >= n_points); "
+                   "call once per row", who);
     const int64_t ld = siren_pad_points(n_points);
     GradPtrs G;
     for (int i = 0; i < N_PARAMS; ++i) G.p[i] = nullptr;
     for (int i = 0; i < SIREN_N_PARAMS; ++i) {
-        NERFMI_REQUIRE(grad_params[i], "siren_backward: grad_params[%d] is null", i);
+        NERFMI_REQUIRE(grad_params[i], "%s: grad_params[%d] is null", who, i);
         G.p[i] = grad_params[i];
     }
     hipStream_t st = (hipStream_t)stream;
@@ -299,20 +407,36 @@ int nerfmi_siren_backward(const float *packed, const float *saved, const float *
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(siren_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             (void)hipGetLastError();
-            set_error("siren_backward: cannot raise the dynamic LDS limit");
+            set_error("%s: cannot raise the dynamic LDS limit", who);
             return NERFMI_E_LAUNCH;
         }
         attr_set.mark(attr_dev);
     }
-    if (points_per_cond >= n_points)
+    if (one_cond)       // the workspace images hold G = dZ / fr; the reduction scales the rows (header of this file)
         hipLaunchKernelGGL(siren_backward_chain_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
                            grad_out, frequencies, n_points, points_per_cond, ld, work);
     else
         hipLaunchKernelGGL(siren_backward_chain_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed,
                            saved, grad_out, frequencies, n_points, points_per_cond, ld, work);
     hipLaunchKernelGGL(siren_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
-    hipLaunchKernelGGL(dw_reduce_kernel<1>, dim3(128, P.n_tasks), dim3(256), 0, st, P, partial, G);
-    return check_launch("siren_backward");
+    hipLaunchKernelGGL(siren_dw_reduce_kernel, dim3(256, SIREN_GROUPS), dim3(256), 0, st, P, partial, G, packed, frequencies,
+                       one_cond ? 1 : 0, grad_frequencies, grad_phase_shifts);
+    return check_launch(who);
+}
+
+int nerfmi_siren_backward(const float *packed, const float *saved, const float *grad_out, const float *frequencies,
+                          int64_t n_points, int64_t points_per_cond, float *const *grad_params, float *workspace,
+                          nerfmi_stream_t stream) {
+    return siren_backward_impl("siren_backward", packed, saved, grad_out, frequencies, n_points, points_per_cond, grad_params,
+                               nullptr, nullptr, workspace, stream);
+}
+
+int nerfmi_siren_backward_cond(const float *packed, const float *saved, const float *grad_out, const float *frequencies,
+                               int64_t n_points, float *const *grad_params, float *grad_frequencies,
+                               float *grad_phase_shifts, float *workspace, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(grad_frequencies && grad_phase_shifts, "siren_backward_cond: null conditioning-gradient pointer");
+    return siren_backward_impl("siren_backward_cond", packed, saved, grad_out, frequencies, n_points, n_points, grad_params,
+                               grad_frequencies, grad_phase_shifts, workspace, stream);
 }
 
 }  // extern "C"

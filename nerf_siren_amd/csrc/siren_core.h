@@ -40,7 +40,7 @@ constexpr int SS_H = 64;                  // 8 x 256 rows: outputs of network.0.
 constexpr int SS_HC = SS_H + 8 * 256;     // 256 rows: output of color_layer_sine
 constexpr int SS_RGB = SS_HC + 256;       // 3 rows (+1 pad): sigmoid output
 // sign bits of cos(freq * pre + phase), 9 x 8 rows, same lane/register map as the NeRF ReLU masks (mlp_layout.h S_MASK):
-// the backward needs d sin = freq * cos(arg); |cos| = sqrt((1 - s)(1 + s)) comes from the saved sine s, the sign from
+// the backward needs d sin = freq * cos(arg); |cos| = sqrt(|1 - s^2|) comes from the saved sine s, the sign from
 // here -- so no second 1 KB/point/layer image of arguments or cosines is written.
 constexpr int SS_MASK = SS_RGB + 4;
 constexpr int SIREN_SAVED_ROWS = SS_MASK + 9 * 8;
@@ -58,18 +58,60 @@ __device__ __forceinline__ void load_mask_row(const RowImage &im, int row, unsig
     mk[0] = v[0]; mk[1] = v[1]; mk[2] = v[2]; mk[3] = v[3];
 }
 
-// FiLM constants of one conditioning row staged in LDS by the workgroup: fr = 15 f + 30 (nerf.py:202) computed ONCE per
-// unit instead of once per (unit, point), and read with ds_read_b128 in the epilogues instead of L2-latency global loads
-// inside the fenced epilogue clumps.  Used when the whole launch shares one conditioning row (COND_LDS; render_rays'
-// SirenField always does); otherwise the rows are read from global memory per lane.
-constexpr int FILM_FLOATS = 2 * 2304;       // [fr 9 x 256][phase 9 x 256]
+// The FiLM activation  sin(fr * pre + phase),  fr = 15 f + 30  (nerf.py:151, :202)  on gfx950 (round 3):
+//   * v_sin_f32 takes its argument in REVOLUTIONS and -- measured on MI355X, tools/ubench/hw_sin.hip,
+//     profiles/r03_ubench_hw_sin.txt -- is accurate to 1.25e-7 absolute (mean 2.8e-8) at every magnitude tried, 0.5 to
+//     100 000 revolutions (the ISA manual's "valid for |t| <= 256" is not a limit of this part): as good as the degree-9
+//     polynomial of rounds 1-2 (sin_pi: 1.4e-7) at TWO issue slots (8 cycles) instead of twelve instructions.  Round 2
+//     assumed it could not hold 1e-4 through nine layers without measuring it.
+//   * the FiLM constants are therefore kept pre-divided by 2 pi:  t = fma(fr', pre, phase'),  fr' = fr / 2pi,
+//     phase' = phase / 2pi  -- one rounding of the argument where the reference makes two (freq * x, + phase); both differ
+//     from the exact argument by ~|arg| * 6e-8.  Two values per instruction: v_pk_fma_f32 issues like v_fma_f32
+//     (tools/ubench/pk_valu.hip, profiles/r03_ubench_pk_valu.txt).
+//   * the sign of cos(arg), which the backward needs beside the saved sine: cos(2 pi t) >= 0  <=>  rint(2 t) is even, and
+//     the parity of rint(2t) is bit 0 of fma(t, 2, 1.5 * 2^23) -- one more packed fma per pair + one v_alignbit per value.
+// Forward epilogue: 2.5 issue slots per value at inference, 4 with the sign bits (rounds 1-2: 14 / 15).  Measured
+// (same box, round 3): forward-with-save 0.725 -> 0.783 of the fp32 MFMA peak, inference 0.77 -> 0.823, step 5.50 -> 5.31 ms.
+constexpr float INV_2PI = 0.15915494309189535f;
+constexpr float RINT_MAGIC = 12582912.0f;    // 1.5 * 2^23: x + MAGIC rounds x to an integer kept in the low mantissa bits
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// fr' = (15 f + 30) / 2pi with the reference's two roundings of fr (nerf.py:202) and one for the division
+__device__ __forceinline__ float film_scale(float f) { return __fmul_rn(__fadd_rn(__fmul_rn(f, 15.0f), 30.0f), INV_2PI); }
+
+// FiLM constants of one conditioning row staged in LDS by the workgroup, computed ONCE per unit instead of once per
+// (unit, point), and read with ds_read_b128 in the epilogues instead of L2-latency global loads inside the fenced epilogue
+// clumps.  Used when the whole launch shares one conditioning row (COND_LDS; render_rays' SirenField always does);
+// otherwise the rows are read from global memory per lane.
+constexpr int FILM_FLOATS = 2 * 2304;       // [fr' 9 x 256][phase' 9 x 256]
 
 __device__ __forceinline__ void stage_film(float *film, const float *__restrict__ freq, const float *__restrict__ phase) {
     for (int i = threadIdx.x; i < 2304; i += blockDim.x) {
-        film[i] = __fadd_rn(__fmul_rn(freq[i], 15.0f), 30.0f);
-        film[2304 + i] = phase[i];
+        film[i] = film_scale(freq[i]);
+        film[2304 + i] = __fmul_rn(phase[i], INV_2PI);
     }
     __syncthreads();
+}
+
+// four FiLM activations: c <- sin(2 pi (fr' c + ph')); SAVE: the sign bits of the cosines are funnel-shifted into `mkw`
+// from the top, ONE instruction per value (v_alignbit: {jbits, mk} >> 1).  After the 32 insertions of blocks 2w, 2w+1 --
+// always in the order q, t -- value (jb, q, t) sits at bit 16*(jb&1) + 4q + t, the layout the chain kernel reads.
+template <bool SAVE>
+__device__ __forceinline__ f32x4 film_sin4(f32x4 c, f32x4 fr, f32x4 ph, unsigned &mkw) {
+    const f32x2 t0 = fma2(f32x2{fr[0], fr[1]}, f32x2{c[0], c[1]}, f32x2{ph[0], ph[1]});
+    const f32x2 t1 = fma2(f32x2{fr[2], fr[3]}, f32x2{c[2], c[3]}, f32x2{ph[2], ph[3]});
+    if (SAVE) {
+        const f32x2 two = {2.0f, 2.0f}, magic = {RINT_MAGIC, RINT_MAGIC};
+        const f32x2 j0 = fma2(t0, two, magic), j1 = fma2(t1, two, magic);
+        mkw = __builtin_amdgcn_alignbit(__float_as_uint(j0[0]), mkw, 1);
+        mkw = __builtin_amdgcn_alignbit(__float_as_uint(j0[1]), mkw, 1);
+        mkw = __builtin_amdgcn_alignbit(__float_as_uint(j1[0]), mkw, 1);
+        mkw = __builtin_amdgcn_alignbit(__float_as_uint(j1[1]), mkw, 1);
+    }
+    return f32x4{__builtin_amdgcn_sinf(t0[0]), __builtin_amdgcn_sinf(t0[1]), __builtin_amdgcn_sinf(t1[0]),
+                 __builtin_amdgcn_sinf(t1[1])};
 }
 
 template <bool FROM_RAYS, bool SIGMA_ONLY, bool SAVE, bool COND_LDS>
@@ -131,17 +173,12 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
                 const f32x4 f = ldg4(fq + 256 * layer + 32 * jb + 8 * q);
                 s = ldg4(ph + 256 * layer + 32 * jb + 8 * q);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) fr[t] = __fadd_rn(__fmul_rn(f[t], 15.0f), 30.0f);      // nerf.py:202
+                for (int t = 0; t < 4; ++t) {
+                    fr[t] = film_scale(f[t]);                                                            // nerf.py:202
+                    s[t] = __fmul_rn(s[t], INV_2PI);
+                }
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                unsigned jbits;
-                c[t] = sin_pi(__fadd_rn(__fmul_rn(fr[t], c[t]), s[t]), jbits);                      // nerf.py:151
-                // sign of cos(arg) = parity of j: funnel-shifted into the mask word from the top, ONE instruction per value
-                // (v_alignbit: {jbits, mk} >> 1).  After the 32 insertions of blocks 2w, 2w+1 -- always in the order q, t --
-                // value (jb, q, t) sits at bit 16*(jb&1) + 4q + t, the layout the chain kernel reads.
-                if (SAVE) mk[jb >> 1] = __builtin_amdgcn_alignbit(jbits, mk[jb >> 1], 1);
-            }
+            c = film_sin4<SAVE>(c, fr, s, mk[jb >> 1]);                                                 // nerf.py:151
             if (SAVE) store_slice(S, (layer < 8 ? SS_H + 256 * layer : SS_HC) + 32 * jb, q, c);
             return c;
         };

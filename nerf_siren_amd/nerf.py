@@ -210,16 +210,25 @@ class SemanticNeRF(nn.Module):
                              "use forward_with_frequencies_phase_shifts")
 
     def forward_with_frequencies_phase_shifts(self, input, frequencies, phase_shifts, ray_directions, **kwargs):
-        """nerf.py:201-216.  Differentiable w.r.t. the 22 parameters; gradients w.r.t. the points, the directions and
-        the conditioning rows (which the reference would get from its never-defined mapping network) are not provided."""
+        """nerf.py:201-216.  Differentiable w.r.t. the 22 parameters and w.r.t. the conditioning rows `frequencies` /
+        `phase_shifts` (which the reference would get from its mapping network, nerf.py:185); gradients w.r.t. the points
+        and the directions are not provided."""
         bz, npts = input.shape[0], input.shape[1]
         pts = input.reshape(-1, 3).contiguous()
         dirs = ray_directions.reshape(-1, 3).contiguous()
         freq, phase = frequencies.reshape(bz, -1).contiguous(), phase_shifts.reshape(bz, -1).contiguous()
         if torch.is_grad_enabled():
-            if any(t.requires_grad for t in (input, frequencies, phase_shifts, ray_directions)):
-                raise NotImplementedError("gradients w.r.t. SIREN inputs / frequencies / phase_shifts are not implemented")
-            if any(p.requires_grad for p in self.parameters()):
+            if input.requires_grad or ray_directions.requires_grad:
+                raise NotImplementedError("gradients w.r.t. the SIREN points / directions are not implemented")
+            cond = freq.requires_grad or phase.requires_grad
+            if cond and bz > 1:
+                # the conditioning gradients come out of a launch that shares ONE row (csrc/siren_bwd.hip): one autograd
+                # node per row; autograd sums the rows' parameter gradients
+                from .rendering import SirenPoints
+                pts3, dirs3 = pts.view(bz, npts, 3), dirs.view(bz, npts, 3)
+                return torch.stack([SirenPoints.apply(self, pts3[r].contiguous(), dirs3[r].contiguous(), freq[r:r + 1],
+                                                      phase[r:r + 1], npts, *self.param_list()) for r in range(bz)])
+            if cond or any(p.requires_grad for p in self.parameters()):
                 from .rendering import SirenPoints
                 return SirenPoints.apply(self, pts, dirs, freq, phase, npts, *self.param_list()).view(bz, npts, 4)
         out = ops.siren_forward_points(self.packed(), pts, dirs, freq, phase, npts)
@@ -243,6 +252,13 @@ class SirenField(nn.Module):
     # the training protocol of rendering.FieldRender / training.FusedAdam / parallel.FlatGradAllReduce
     def param_list(self):
         return self.model.param_list()
+
+    def cond_param_list(self):
+        """[frequencies, phase_shifts] when either is trainable (`.requires_grad_(True)`), else []: render_rays then
+        differentiates through the FiLM conditioning as the reference's autograd does (nerf.py:147-151)."""
+        if self.frequencies.requires_grad or self.phase_shifts.requires_grad:
+            return [self.frequencies, self.phase_shifts]
+        return []
 
     def mark_parameters_changed(self):
         self.model.mark_parameters_changed()

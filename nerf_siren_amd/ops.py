@@ -91,21 +91,43 @@ def sample_stratified(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand
     return z
 
 
-_DRAW_OFFSET = {}
+def _generator(device):
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return torch.cuda.default_generators[idx]
 
 
 def next_draw_key(device):
-    """(seed, offset) of the next render_rays call on `device`: seed = torch.initial_seed() (torch.manual_seed controls
-    it), offset = a per-device call counter."""
-    offset = _DRAW_OFFSET.get(device, 0)
-    _DRAW_OFFSET[device] = offset + 1
-    return torch.initial_seed(), offset
+    """(seed, offset) of the next render_rays call on `device`, taken from -- and advancing -- torch's own CUDA generator
+    of that device: seed = its seed, offset = its Philox offset in units of four 32-bit draws (one unit per call; the
+    kernels derive every draw of the call from (seed, offset, segment, element), csrc/rays.hip).  So the draws obey
+    torch.manual_seed / torch.cuda.manual_seed (offset back to 0), torch.cuda.get_rng_state / set_rng_state carry them
+    across a checkpoint (a resumed run continues the stream instead of replaying it), and torch's own random ops on the
+    device and this path never hand out the same offset twice."""
+    gen = _generator(device)
+    off = gen.get_offset()
+    gen.set_offset(off + 4)
+    return gen.initial_seed(), off // 4
+
+
+def get_draw_state(device):
+    """{'seed', 'offset'} of the next draw key of `device` (what a checkpoint stores; torch.cuda.get_rng_state(device) holds
+    the same information)."""
+    gen = _generator(device)
+    return {"seed": gen.initial_seed(), "offset": gen.get_offset() // 4}
+
+
+def set_draw_state(device, state):
+    """Restore get_draw_state()'s dict: the next render_rays call on `device` draws what it would have drawn then."""
+    gen = _generator(device)
+    gen.manual_seed(int(state["seed"]))
+    gen.set_offset(int(state["offset"]) * 4)
 
 
 def render_draws(device, n_rays, S, F, perturb=True, noise=True, seed=None, offset=None):
     """The random draws of one render_rays call from ONE launch (nerfmi_render_draws): dict with 'perturb_rand' (N,S),
     'u' (N,F) when `perturb`, 'noise_coarse' (N,S), 'noise_fine' (N,S+F) when `noise` -- views of one allocation.
-    seed defaults to torch.initial_seed() (torch.manual_seed controls it), offset to a per-device call counter."""
+    seed / offset default to next_draw_key(device): torch's CUDA generator of the device (torch.manual_seed controls it)."""
     if seed is None or offset is None:
         k = next_draw_key(device)
         seed = k[0] if seed is None else seed
@@ -373,8 +395,10 @@ def siren_forward_points_train(packed, points, dirs, freq, phase, points_per_con
     return out, saved
 
 
-def siren_backward(packed, saved, grad_out, freq, points_per_cond, grads=None):
-    """-> list of 22 gradient tensors (SIREN_PARAM_ORDER), written not accumulated."""
+def siren_backward(packed, saved, grad_out, freq, points_per_cond, grads=None, cond_grads=False):
+    """-> list of 22 gradient tensors (SIREN_PARAM_ORDER), written not accumulated.
+    cond_grads=True (the launch must share ONE conditioning row): -> (grads, d frequencies (1, 2304), d phase_shifts (1, 2304))
+    through nerfmi_siren_backward_cond."""
     grad_out = _req(grad_out, "grad_out", (None, 4))
     n = grad_out.shape[0]
     freq = _req(freq, "frequencies", (None, 2304))
@@ -385,6 +409,14 @@ def siren_backward(packed, saved, grad_out, freq, points_per_cond, grads=None):
     if grads is None:
         grads = siren_flat_views(torch.empty(SIREN_PARAM_NUMEL, device=grad_out.device, dtype=torch.float32))
     ws = torch.empty(_lib.lib().nerfmi_siren_backward_workspace_floats(n), device=grad_out.device, dtype=torch.float32)
+    if cond_grads:
+        if points_per_cond < n:
+            raise ValueError("siren_backward(cond_grads=True) needs a launch that shares one conditioning row")
+        d_cond = torch.empty((2, 2304), device=grad_out.device, dtype=torch.float32)
+        check(_lib.lib().nerfmi_siren_backward_cond(ptr(packed), ptr(saved), ptr(grad_out), ptr(freq), n, _ptr_array(grads),
+                                                    ptr(d_cond[0]), ptr(d_cond[1]), ptr(ws), _stream(grad_out)),
+              "siren_backward_cond")
+        return grads, d_cond[0:1], d_cond[1:2]
     check(_lib.lib().nerfmi_siren_backward(ptr(packed), ptr(saved), ptr(grad_out), ptr(freq), n, int(points_per_cond),
                                            _ptr_array(grads), ptr(ws), _stream(grad_out)), "siren_backward")
     return grads

@@ -70,8 +70,10 @@ class FlatGradAllReduce:
             for i, (m, n) in enumerate(zip(self.models, sizes)):
                 m._grad_target = self.joint[off:off + n]
                 off += n
-                if self.overlap:
-                    m._grad_ready_hook = (lambda target, i=i: self._launch(i, target))
+                # a model belongs to the LAST reducer built over it: an earlier overlapping reducer's hook must not keep
+                # launching collectives into that reducer's stale bookkeeping
+                m._grad_ready_hook = (lambda target, i=i: self._launch(i, target)) if self.overlap else None
+                m._grad_target_claimed = False
 
     def _launch(self, i, target):
         """Called by the model's backward right after its gradient kernels were enqueued into `target`."""
@@ -84,7 +86,11 @@ class FlatGradAllReduce:
         bases, loose = [], []
         for m in self.models:
             ps = list(m.param_list()) if hasattr(m, "param_list") else list(m.parameters())
+            listed = {id(p) for p in ps}
             ps = [p for p in ps if p.requires_grad and p.grad is not None]
+            # trainable tensors outside the flat layout (a SirenField's conditioning rows): reduced with the loose ones
+            extra = [p for p in m.parameters() if id(p) not in listed and p.requires_grad and p.grad is not None]
+            loose.extend(extra)
             if not ps:
                 continue
             b = flat_grad_alias(ps)
@@ -94,7 +100,22 @@ class FlatGradAllReduce:
                 loose.extend(ps)
         return bases, loose
 
+    def reset(self):
+        """Step boundary: forget collectives launched by a backward pass that never reached all_reduce() (an exception
+        mid-backward) and release the models' gradient targets, so the next step starts clean instead of failing with
+        'applied more than once'."""
+        for w in self._works.values():
+            try:
+                w.wait()
+            except Exception:
+                pass
+        self._works = {}
+        for m in self.models:
+            if hasattr(m, "_grad_target_claimed"):
+                m._grad_target_claimed = False
+
     def zero_(self):
+        self.reset()
         for p in self.params:
             p.grad = None
 
@@ -104,8 +125,9 @@ class FlatGradAllReduce:
         (training.FusedAdam.step(grad_scale=1/world)) and saves a pass over the gradients."""
         bases, loose = self._bases()
         works, self._works = self._works, {}
-        if self.joint is not None and not loose and len(bases) == len(self.models) and all(
+        if self.joint is not None and len(bases) == len(self.models) and all(
                 b.data_ptr() == m._grad_target.data_ptr() for b, m in zip(bases, self.models)):
+            self._reduce_loose(loose, average)
             if self.world > 1:
                 if works:                       # slices already on the wire: wait for them, reduce the others now
                     for i, m in enumerate(self.models):
@@ -126,16 +148,20 @@ class FlatGradAllReduce:
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
                 if average:
                     b.mul_(1.0 / self.world)
-            if loose:
-                flat = torch.cat([p.grad.reshape(-1) for p in loose])
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-                if average:
-                    flat.mul_(1.0 / self.world)
-                off = 0
-                for p in loose:
-                    p.grad.copy_(flat[off:off + p.grad.numel()].view_as(p.grad))
-                    off += p.grad.numel()
+            self._reduce_loose(loose, average)
         return bases
+
+    def _reduce_loose(self, loose, average):
+        if self.world <= 1 or not loose:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in loose])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if average:
+            flat.mul_(1.0 / self.world)
+        off = 0
+        for p in loose:
+            p.grad.copy_(flat[off:off + p.grad.numel()].view_as(p.grad))
+            off += p.grad.numel()
 
 
 def shard_rays(n_total: int, rank: int, world: int):

@@ -93,6 +93,7 @@ class FieldRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays, z, noise, noise_std, white_back, *params):
         siren = hasattr(model, "field_rays")
+        ctx.n_field_params = len(model.param_list())      # SirenField may append its trainable conditioning rows behind them
         if siren:
             packed = model.model.packed()
             field, saved = ops.siren_forward_rays_train(packed, rays, z, model.frequencies, model.phase_shifts, rays.shape[0])
@@ -122,21 +123,28 @@ class FieldRender(torch.autograd.Function):
         rays, z, noise, field, saved, packed = ctx.saved_tensors
         has_noise, noise_std, white_back, siren = ctx.cfg
         n_params = len(ops.SIREN_PARAM_ORDER if siren else ops.PARAM_ORDER)
+        n_cond = len(ctx.needs_input_grad) - 6 - n_params            # 0, or 2: SirenField's frequencies, phase_shifts
         if g_rgb is None and g_depth is None and g_opacity is None:
-            return (None,) * (6 + n_params)
+            return (None,) * (6 + n_params + n_cond)
         grad_field = ops.composite_backward(field, z, rays, noise if has_noise else None, noise_std, white_back,
                                             g_rgb, g_depth, g_opacity, philox=ctx.philox)
         out = _claim_grad_target(ctx.model, rays.device)
-        if siren:
+        cond = ()
+        if siren and n_cond:
+            grads, d_f, d_p = ops.siren_backward(packed, saved, grad_field, ctx.model.frequencies, z.numel(), grads=out,
+                                                 cond_grads=True)
+            cond = (d_f.view_as(ctx.model.frequencies), d_p.view_as(ctx.model.phase_shifts))
+        elif siren:
             grads = ops.siren_backward(packed, saved, grad_field, ctx.model.frequencies, z.numel(), grads=out)
         else:
             grads = ops.nerf_backward_rays(packed, rays, z, saved, grad_field, grads=out, fast=ctx.fast)
         _grad_ready(ctx.model, out)
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads, *cond)
 
 
 class SirenPoints(torch.autograd.Function):
-    """SemanticNeRF.forward_with_frequencies_phase_shifts (nerf.py:201-216) with autograd w.r.t. the 22 parameters."""
+    """SemanticNeRF.forward_with_frequencies_phase_shifts (nerf.py:201-216) with autograd w.r.t. the 22 parameters and --
+    when the call shares one conditioning row -- w.r.t. that row (frequencies, phase_shifts)."""
 
     @staticmethod
     def forward(ctx, model, points, dirs, freq, phase, points_per_cond, *params):
@@ -150,9 +158,13 @@ class SirenPoints(torch.autograd.Function):
     def backward(ctx, g_out):
         saved, packed, freq = ctx.saved_tensors
         out = _claim_grad_target(ctx.model, g_out.device)
-        grads = ops.siren_backward(packed, saved, g_out.contiguous(), freq, ctx.ppc, grads=out)
+        d_f = d_p = None
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            grads, d_f, d_p = ops.siren_backward(packed, saved, g_out.contiguous(), freq, ctx.ppc, grads=out, cond_grads=True)
+        else:
+            grads = ops.siren_backward(packed, saved, g_out.contiguous(), freq, ctx.ppc, grads=out)
         _grad_ready(ctx.model, out)
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, d_f, d_p, None, *grads)
 
 
 class EmbeddedField(torch.autograd.Function):
@@ -218,8 +230,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     train = torch.is_grad_enabled() and any(p.requires_grad for m in models for p in m.parameters())
 
     # Random draws (rendering.py:221 rand, :170 randn, :47 rand, :170 randn): injected tensors win (parity tests); every
-    # other draw is made INSIDE the consuming kernel from one Philox key per call (seed = torch.initial_seed(), offset =
-    # a per-device call counter) -- no aten distribution launches, no tensors of draws.
+    # other draw is made INSIDE the consuming kernel from one Philox key per call (seed and offset of torch's CUDA
+    # generator of the device, which the call advances: ops.next_draw_key) -- no aten distribution launches, no tensors of draws.
     draw_key = ops.next_draw_key(dev) if (perturb != 0 or noise_std != 0) else None
     pr = _rng(rng, "perturb_rand", (N, S)) if perturb > 0 else None
     z = ops.sample_stratified(rays, S, use_disp, float(perturb), pr, philox=draw_key)
@@ -234,9 +246,10 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
 
     def full_pass(model, zz, key, seg):
         noise, philox = noise_for(key, zz.shape[1], seg)
-        if train and any(p.requires_grad for p in model.param_list()):
+        if train and any(p.requires_grad for p in model.parameters()):
+            cond = model.cond_param_list() if hasattr(model, "cond_param_list") else []
             rgb, depth, opacity, weights = FieldRender.apply(model, rays, zz, noise if philox is None else philox,
-                                                            float(noise_std), bool(white_back), *model.param_list())
+                                                            float(noise_std), bool(white_back), *model.param_list(), *cond)
         elif hasattr(model, "field_rays"):                     # FiLM-SIREN adapter (nerf.SirenField)
             field = model.field_rays(rays, zz, sigma_only=False)
             weights, rgb, depth, opacity = ops.composite(field, zz, rays, noise, noise_std, white_back, philox=philox)

@@ -412,7 +412,7 @@ def film_layer(w, b, x, freq, phase, keep: bool = False):
     y = (x @ w.T + b).astype(F32)
     arg = ((freq[:, None, :] * y).astype(F32) + phase[:, None, :]).astype(F32)
     out = np.sin(arg.astype(F64)).astype(F32)
-    return (out, arg) if keep else out
+    return (out, arg, y) if keep == "pre" else ((out, arg) if keep else out)
 
 
 def siren_forward(p: dict, inp, frequencies, phase_shifts, ray_directions, sigma_only: bool = False,
@@ -424,32 +424,42 @@ def siren_forward(p: dict, inp, frequencies, phase_shifts, ray_directions, sigma
     fr = ((np.asarray(frequencies, F32) * F32(15)).astype(F32) + F32(30)).astype(F32)       # nerf.py:202
     ph = np.asarray(phase_shifts, F32)
     x = (inp * F32(2.0 / 51.0)).astype(F32)                                                   # UniformBoxWarp(51), :134-140,:193
-    xs, args = [], []
+    xs, args, pres = [], [], []
     for i in range(8):
         xs.append(x)
-        x, a = film_layer(p[f"network.{i}.layer.weight"], p[f"network.{i}.layer.bias"], x,
-                          fr[:, i * H:(i + 1) * H], ph[:, i * H:(i + 1) * H], keep=True)
+        x, a, y = film_layer(p[f"network.{i}.layer.weight"], p[f"network.{i}.layer.bias"], x,
+                             fr[:, i * H:(i + 1) * H], ph[:, i * H:(i + 1) * H], keep="pre")
         args.append(a)
+        pres.append(y)
     sigma = (x @ p["final_layer.weight"].T + p["final_layer.bias"]).astype(F32)
     if sigma_only:
         return (sigma, dict(xs=xs, args=args, h=x, fr=fr)) if keep else sigma
     cin = np.concatenate([np.asarray(ray_directions, F32), x], -1)                            # :213
-    c, carg = film_layer(p["color_layer_sine.layer.weight"], p["color_layer_sine.layer.bias"], cin, fr[:, -H:], ph[:, -H:],
-                         keep=True)
+    c, carg, cpre = film_layer(p["color_layer_sine.layer.weight"], p["color_layer_sine.layer.bias"], cin, fr[:, -H:],
+                               ph[:, -H:], keep="pre")
     pre = (c @ p["color_layer_linear.0.weight"].T + p["color_layer_linear.0.bias"]).astype(F32)
     rgb = (F32(1) / (F32(1) + np.exp(-pre.astype(F64)))).astype(F32)
     out = np.concatenate([rgb, sigma], -1).astype(F32)
     if keep:
-        return out, dict(xs=xs, args=args, h=x, fr=fr, cin=cin, c=c, carg=carg, rgb=rgb)
+        return out, dict(xs=xs, args=args, pres=pres, h=x, fr=fr, cin=cin, c=c, carg=carg, cpre=cpre, rgb=rgb)
     return out
 
 
-def siren_backward(p: dict, cache: dict, grad_out: np.ndarray) -> dict:
+def siren_backward(p: dict, cache: dict, grad_out: np.ndarray, cond: bool = False):
     """Manual backward of siren_forward (autograd of nerf.py:142-151, :201-216) w.r.t. the 22 parameters.
-    grad_out (Bz,Np,4) = [d rgb, d sigma].  d/dz sin(fr*z + ph) = fr * cos(fr*z + ph)."""
+    grad_out (Bz,Np,4) = [d rgb, d sigma].  d/dz sin(fr*z + ph) = fr * cos(fr*z + ph).
+    cond=True: -> (parameter gradients, d frequencies (Bz, 9*256), d phase_shifts (Bz, 9*256)): with fr = 15 f + 30 (:202)
+    d/d ph = cos(arg), d/d f = 15 z cos(arg), each summed over the points of its conditioning row."""
     H = 256
     fr = cache["fr"]
     g = {}
+    d_f = np.zeros(fr.shape, F64)
+    d_p = np.zeros(fr.shape, F64)
+
+    def cond_grads(sl, d_act, arg, pre):
+        gc = d_act.astype(F64) * np.cos(arg.astype(F64))                                      # (Bz, Np, H)
+        d_p[:, sl] = gc.sum(1)
+        d_f[:, sl] = 15.0 * (gc * pre.astype(F64)).sum(1)
 
     def flat(a):
         return a.reshape(-1, a.shape[-1])
@@ -461,6 +471,7 @@ def siren_backward(p: dict, cache: dict, grad_out: np.ndarray) -> dict:
     g["color_layer_linear.0.bias"] = flat(d_pre).sum(0)
     d_c = d_pre @ p["color_layer_linear.0.weight"]
     dz = (d_c * fr[:, None, -H:] * np.cos(cache["carg"].astype(F64)).astype(F32)).astype(F32)
+    cond_grads(slice(8 * H, 9 * H), d_c, cache["carg"], cache["cpre"])
     g["color_layer_sine.layer.weight"] = flat(dz).T @ flat(cache["cin"])                      # columns [dir 3 | hidden 256], :213
     g["color_layer_sine.layer.bias"] = flat(dz).sum(0)
     d_h = (dz @ p["color_layer_sine.layer.weight"])[..., 3:] + d_sigma @ p["final_layer.weight"]
@@ -468,11 +479,13 @@ def siren_backward(p: dict, cache: dict, grad_out: np.ndarray) -> dict:
     g["final_layer.bias"] = flat(d_sigma).sum(0)
     for i in reversed(range(8)):
         dz = (d_h * fr[:, None, i * H:(i + 1) * H] * np.cos(cache["args"][i].astype(F64)).astype(F32)).astype(F32)
+        cond_grads(slice(i * H, (i + 1) * H), d_h, cache["args"][i], cache["pres"][i])
         g[f"network.{i}.layer.weight"] = flat(dz).T @ flat(cache["xs"][i])
         g[f"network.{i}.layer.bias"] = flat(dz).sum(0)
         if i:
             d_h = dz @ p[f"network.{i}.layer.weight"]
-    return {k: np.asarray(v, F32) for k, v in g.items()}
+    g = {k: np.asarray(v, F32) for k, v in g.items()}
+    return (g, d_f.astype(F32), d_p.astype(F32)) if cond else g
 
 
 # ----------------------------------------------------------------------------

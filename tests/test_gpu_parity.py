@@ -597,6 +597,66 @@ def test_siren_backward_vs_reference_autograd(golden, dev, siren):
         m.forward_with_frequencies_phase_shifts(args[0].requires_grad_(True), *args[1:])
 
 
+def test_siren_conditioning_gradients_vs_reference_autograd(golden, dev, siren):
+    """Round 3 (verdict item 5): forward_with_frequencies_phase_shifts is differentiable in `frequencies` / `phase_shifts`
+    (nerf.py:147-151, :201-216 under torch autograd).  Fixture g8b holds the REFERENCE's autograd gradients of both
+    (3 conditioning rows x 2304) for loss = sum(out * G); the HIP path derives them from the dW slabs (csrc/siren_bwd.hip:
+    d ph = sum_p G, d f = 15 (<W_j, (G^T X)_j> + b_j sum_p G_j)).  Also: the 22 parameter gradients of the same pass (now
+    summed by autograd over three one-row launches) still match, a single-row call runs as ONE launch, and the run is
+    bit-reproducible."""
+    g, gg = golden("g8_siren"), golden("g8b_siren_grad")
+    p, m = siren
+    m.zero_grad()
+    inp, dirs = T(g["inp"], dev), T(g["dirs"], dev)
+    o, cache = O.siren_forward(p, g["inp"], g["freq"], g["phase"], g["dirs"], keep=True)
+    og, o_f, o_p = O.siren_backward(p, cache, gg["G"], cond=True)
+    runs = []
+    for _ in range(2):
+        m.zero_grad()
+        freq, phase = T(g["freq"], dev).requires_grad_(True), T(g["phase"], dev).requires_grad_(True)
+        out = m.forward_with_frequencies_phase_shifts(inp, freq, phase, dirs)
+        np.testing.assert_allclose(N(out), gg["out"], atol=1e-4)
+        (out * T(gg["G"], dev)).sum().backward()
+        assert freq.grad.shape == (3, 2304) and phase.grad.shape == (3, 2304)
+        runs.append((N(freq.grad).copy(), N(phase.grad).copy(), {k: N(q.grad).copy() for k, q in m.named_parameters()}))
+    d_f, d_p, d_w = runs[0]
+    for name, v, ref, orc in (("frequencies", d_f, gg["cond_grad_frequencies"], o_f),
+                              ("phase_shifts", d_p, gg["cond_grad_phase_shifts"], o_p)):
+        r_ref, r_or = _rel(v, ref), _rel(v, orc)
+        assert r_ref < 2e-4 and r_or < 2e-4, (name, r_ref, r_or)
+        for layer in range(9):                          # every layer's 256-slice on its own (the colour layer has two dW tasks)
+            sl = slice(256 * layer, 256 * (layer + 1))
+            assert _rel(v[:, sl], ref[:, sl]) < 5e-4, (name, layer, _rel(v[:, sl], ref[:, sl]))
+    for k, v in d_w.items():
+        assert _rel(v, gg["grad_" + k]) < 2e-4, (k, _rel(v, gg["grad_" + k]))
+    assert np.array_equal(d_f, runs[1][0]) and np.array_equal(d_p, runs[1][1])
+    assert all(np.array_equal(d_w[k], runs[1][2][k]) for k in d_w)
+    # one conditioning row -> one autograd node, one backward launch: row 1 alone equals its slice of the three-row result
+    m.zero_grad()
+    f1, p1 = T(g["freq"][1:2], dev).requires_grad_(True), T(g["phase"][1:2], dev).requires_grad_(True)
+    out1 = m.forward_with_frequencies_phase_shifts(inp[1:2], f1, p1, dirs[1:2])
+    (out1 * T(gg["G"][1:2], dev)).sum().backward()
+    assert np.array_equal(N(f1.grad), d_f[1:2]) and np.array_equal(N(p1.grad), d_p[1:2])
+    # only the conditioning trainable (frozen field, the pi-GAN mapping-network case): same conditioning gradients
+    for q in m.parameters():
+        q.requires_grad_(False)
+    try:
+        f2, p2 = T(g["freq"][1:2], dev).requires_grad_(True), T(g["phase"][1:2], dev).requires_grad_(True)
+        (m.forward_with_frequencies_phase_shifts(inp[1:2], f2, p2, dirs[1:2]) * T(gg["G"][1:2], dev)).sum().backward()
+        assert np.array_equal(N(f2.grad), d_f[1:2]) and np.array_equal(N(p2.grad), d_p[1:2])
+    finally:
+        for q in m.parameters():
+            q.requires_grad_(True)
+        m.zero_grad()
+    # the C ABI refuses conditioning gradients for a launch with several rows
+    from nerf_siren_amd import ops as o_
+    pk = m.packed()
+    pts = inp.reshape(-1, 3).contiguous()
+    _, saved = o_.siren_forward_points_train(pk, pts, dirs.reshape(-1, 3).contiguous(), T(g["freq"], dev), T(g["phase"], dev), 41)
+    with pytest.raises(ValueError):
+        o_.siren_backward(pk, saved, T(gg["G"].reshape(-1, 4), dev), T(g["freq"], dev), 41, cond_grads=True)
+
+
 @pytest.mark.parametrize("n_rays", [37, 200])
 def test_siren_render_rays_training(dev, n_rays):
     """render_rays([SirenField, SirenField]) in training mode (perturb, noise, white_back) against the oracle pipeline:
@@ -652,6 +712,27 @@ def test_siren_render_rays_training(dev, n_rays):
             r = _rel(N(q.grad), og[k])
             assert r < 5e-4, (tag, k, r)
         assert fields[i].frequencies.grad is None
+    # round 3: trainable conditioning rows through render_rays (SirenField.frequencies / phase_shifts .requires_grad_(True)):
+    # same pass, gradients of both rows of both fields against the oracle; the 22 parameter gradients do not change
+    before = [{k: N(q.grad).copy() for k, q in f.model.named_parameters()} for f in fields]
+    for f in fields:
+        f.zero_grad()
+        f.frequencies.requires_grad_(True)
+        f.phase_shifts.requires_grad_(True)
+    res = render_rays(fields, emb, T(rays, dev), S, False, 1.0, 1.0, F, 1024 * 32, True, False, rng=hr)
+    sum((res[k] * T(G[k], dev)).sum() for k in res).backward()
+    for tag, i, cres, cache in (("coarse", 0, cc, cache_c), ("fine", 1, cf, cache_f)):
+        d_s, d_rgb = O.composite_backward(cres["_cache"], cres["weights"], G["rgb_" + tag], G["depth_" + tag],
+                                          G["opacity_" + tag], True)
+        _, o_f, o_p = O.siren_backward(ps[i], cache, np.concatenate([d_rgb, d_s[..., None]], -1).reshape(1, -1, 4), cond=True)
+        r_f, r_p = _rel(N(fields[i].frequencies.grad), o_f), _rel(N(fields[i].phase_shifts.grad), o_p)
+        assert r_f < 5e-4 and r_p < 5e-4, (tag, r_f, r_p)
+        for k, q in fields[i].model.named_parameters():
+            assert np.array_equal(N(q.grad), before[i][k]), (tag, k)
+    for f in fields:
+        f.frequencies.requires_grad_(False)
+        f.phase_shifts.requires_grad_(False)
+        f.zero_grad()
     # a short optimisation run through the same path makes progress (FusedAdam on the SIREN parameters)
     from nerf_siren_amd.training import FusedAdam
     opt = FusedAdam(fields, lr=1e-4)
@@ -1829,7 +1910,7 @@ def test_render_draws_philox(ops, dev):
 
 def test_render_rays_draws_on_device(dev, models):
     """Without injected draws render_rays draws INSIDE its kernels (sampler jitter, compositor noise forward AND
-    backward, resampling u) from Philox streams keyed by torch.manual_seed and a per-device call counter: the same seed and
+    backward, resampling u) from Philox streams keyed by the seed and offset of torch's CUDA generator (ops.next_draw_key): the same seed and
     call count give the same image, a later call different noise, and -- the strong check -- the image AND the parameter
     gradients are bit-identical to a run that is handed the same streams as tensors (nerfmi_render_draws)."""
     from nerf_siren_amd import Embedding, render_rays
@@ -1843,10 +1924,8 @@ def test_render_rays_draws_on_device(dev, models):
         with (torch.enable_grad() if grad else torch.no_grad()):
             return render_rays(ms, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, True, False, **kw)
     torch.manual_seed(77)
-    o._DRAW_OFFSET.clear()
     a, b = run(), run()
     torch.manual_seed(77)
-    o._DRAW_OFFSET.clear()
     c = run()
     assert torch.equal(a["rgb_fine"], c["rgb_fine"]) and not torch.equal(a["rgb_fine"], b["rgb_fine"])
     assert all(torch.isfinite(v).all() for v in a.values())
@@ -1856,7 +1935,6 @@ def test_render_rays_draws_on_device(dev, models):
         assert torch.equal(a[k], d[k]), k
     # test_time (sigma-only compositor) draws the same coarse noise
     torch.manual_seed(77)
-    o._DRAW_OFFSET.clear()
     with torch.no_grad():
         t1 = render_rays(ms, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, True, True)
         t2 = render_rays(ms, emb, rays, 64, False, 1.0, 1.0, 64, 1024 * 32, True, True, rng=inj)
@@ -1866,7 +1944,6 @@ def test_render_rays_draws_on_device(dev, models):
     grads = []
     for kw in ({}, {"rng": inj}):
         torch.manual_seed(77)
-        o._DRAW_OFFSET.clear()
         for m in ms:
             m.zero_grad()
         r = run(grad=True, **kw)
@@ -1877,7 +1954,6 @@ def test_render_rays_draws_on_device(dev, models):
         m.zero_grad()
     # partial injection: the other draws still come from the key
     torch.manual_seed(77)
-    o._DRAW_OFFSET.clear()
     e = run(rng={"u": inj["u"]})
     for k in a:
         assert torch.equal(a[k], e[k]), k

@@ -227,13 +227,19 @@ def test_siren_backward_oracle_vs_reference_autograd(golden):
     p = synth.siren_params(3)
     out, cache = O.siren_forward(p, g["inp"], g["freq"], g["phase"], g["dirs"], keep=True)
     assert np.abs(out - gg["out"]).max() < 2e-6
-    grads = O.siren_backward(p, cache, gg["G"])
+    grads, d_f, d_p = O.siren_backward(p, cache, gg["G"], cond=True)
     assert set(grads) == set(p)
     for k, v in grads.items():
         ref = gg["grad_" + k]
         assert v.shape == ref.shape, k
         rel = np.linalg.norm((v - ref).astype(np.float64)) / max(np.linalg.norm(ref.astype(np.float64)), 1e-30)
         assert rel < 2e-5, (k, rel)
+    # round 3: the conditioning rows (three rows x 9 x 256) against the reference's autograd of the same loss
+    for name, v in (("frequencies", d_f), ("phase_shifts", d_p)):
+        ref = gg["cond_grad_" + name]
+        assert v.shape == ref.shape == (3, 2304), name
+        rel = np.linalg.norm((v - ref).astype(np.float64)) / np.linalg.norm(ref.astype(np.float64))
+        assert rel < 2e-5, (name, rel)
 
 
 # --------------------------------------------------------------------------- f2: loss + Adam

@@ -318,10 +318,13 @@ def g_siren():
     # loss = sum(out * G), inputs as above (three conditioning rows, 41 points each)
     G = synth.hash_normal((Bz, Np, 4), 205)
     m.zero_grad()
-    o = m.forward_with_frequencies_phase_shifts(torch.from_numpy(inp), torch.from_numpy(freq), torch.from_numpy(phase),
-                                                torch.from_numpy(dirs))
+    # round 3: the conditioning rows are differentiable in the reference too (its mapping network would sit upstream,
+    # nerf.py:185): their autograd gradients are part of the fixture
+    tf, tp = torch.from_numpy(freq).requires_grad_(True), torch.from_numpy(phase).requires_grad_(True)
+    o = m.forward_with_frequencies_phase_shifts(torch.from_numpy(inp), tf, tp, torch.from_numpy(dirs))
     (o * torch.from_numpy(G)).sum().backward()
-    save("g8b_siren_grad", G=G, out=o, **{"grad_" + k: q.grad for k, q in m.named_parameters()})
+    save("g8b_siren_grad", G=G, out=o, cond_grad_frequencies=tf.grad, cond_grad_phase_shifts=tp.grad,
+         **{"grad_" + k: q.grad for k, q in m.named_parameters()})
 
 
 # --------------------------------------------------------------------------- G9..G14 (EG3D)
