@@ -1,29 +1,31 @@
 #!/usr/bin/env python
-"""Headline benchmark: ray-samples/s of render_rays() on Blender-lego-like rays
-(400x400 pinhole, N_samples=64 + N_importance=64), BASELINE.json configs[1]
-(batch 1024 rays per GPU), synthetic rays and seeded random-init weights.
+"""Headline benchmark: ray-samples/s of render_rays() on Blender-lego-like rays (400x400 pinhole, N_samples=64 +
+N_importance=64), BASELINE.json configs[1] -- "SIREN-MLP, batch_size=1024, 1xMI355X" -- synthetic rays and seeded
+random-init weights.  The headline field is the reference's FiLM-SIREN field (models/nerf.py:142-216, 9 FiLM layers x 256)
+behind render_rays; the reference's live ReLU NeRF 8x256 (system.py:181-192) runs beside it as the `nerf` object.
 
-One "step" = one pass of the hot path over one batch of 1024 rays per rank:
-  --mode train (default): render_rays forward (coarse+fine, perturb=1,
-      noise_std=1) + MSE(coarse)+MSE(fine) + backward through both MLPs +
-      gradient all-reduce (RCCL, N>1; the fine model's slice goes on the wire while the
-      coarse model's backward runs) + Adam step  -- system.py:257-275
-  --mode infer: render_rays(test_time=True, perturb=0, noise_std=0) under
-      no_grad -- eval.py:85-96
+One "step" = one pass of the hot path over one batch of rays per rank:
+  --mode train (default): render_rays forward (coarse+fine, perturb=1, noise_std=1) + MSE(coarse)+MSE(fine) + backward
+      through both fields + gradient all-reduce (RCCL, N>1; the fine model's slice goes on the wire while the coarse
+      model's backward runs) + Adam step  -- system.py:257-275
+  --mode infer: render_rays(test_time=True, perturb=0, noise_std=0) under no_grad -- eval.py:85-96
 A ray-sample = one field evaluation: 64 coarse + 128 fine = 192 per ray.
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (a child
 `python -m torch.distributed.run`, before this process makes any GPU call) and relays rank 0's JSON line; under
-torch.distributed.run it is one rank.
+torch.distributed.run it is one rank.  --scaling weak (default): --batch rays per rank; --scaling strong: --global-batch
+rays (default 8192, configs[2]) split over the ranks.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fine NeRF MLP forward, fp32 MFMA bound):
-algorithmic FLOPs per launch / its average duration measured with HIP events on the launch stream inside the timed
-region (ops.set_profile_hook).  Beside the headline, at N = 1: `infer` (the same field at test time), `siren` (the
-FiLM-SIREN field of configs[1]: training and inference steps + the roofline of siren_forward_kernel), `eg3d`
-(configs[4]: ImportanceRenderer forward / forward+backward / dense 128^3 query with the gather roofline of
-triplane_kernel), `opt_in` (split-bf16 math), `psnr` (committed teacher-scene protocol) and `cpu_baseline` = the
-reference's CPU PyTorch path restated op for op (oracle/torch_cpu_ref.py) on this box's physical cores, on a bounded
-sample of the same workload.
+Prints ONE JSON line (rank 0).  `roofline`: all three training kernels of the field (forward-with-save, dX chain, dW GEMM;
+inference: the two forward kernels) from HIP events recorded by the library on the launch stream INSIDE the timed region
+(nerfmi_profile_start/report, csrc/render.hip): algorithmic FLOPs of the launches / their measured time, against the dense
+fp32 MFMA peak; `roofline.kernel` names the kernel with the largest share of the step and `roofline.frac` is ITS fraction
+(what `rocprofv3 --kernel-trace --stats` gives as FLOPs x points / (launches x AverageNs)); `roofline.step` is the
+step-level fraction FLOP/step / ms_per_step / peak.  Beside the headline, at N = 1: `infer` (the same field at test time),
+`nerf` (the reference's live ReLU NeRF: training + inference, same roofline breakdown), `eg3d` (configs[4]), `opt_in`
+(split-bf16 math), `psnr` (committed teacher-scene protocols) and `cpu_baseline` = the reference's CPU PyTorch path on the
+SAME workload restated op for op (oracle/torch_cpu_ref.py) on this box's cores, on a bounded sample.  At N > 1: `dist`
+(what torch.distributed / RCCL saw) and `comm` (the all-reduce alone and its exposed part under overlap).
 """
 import argparse
 import json
@@ -36,13 +38,36 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_FULL = 1_186_816        # NeRF full forward per sample
-FLOP_SIGMA = 982_528         # sigma-only forward per sample
-FLOP_TRAIN = 3_489_024       # fwd + dW + dX per sample
-FLOP_SIREN = 1_053_696       # FiLM-SIREN full forward per sample (+2 304 sin)
+# algorithmic FLOPs per sample (2 x multiply-adds of the dense layers)
+FLOP = {
+    "nerf": {"fwd": 1_186_816, "fwd_sigma": 982_528, "chain": 1_115_392, "dw": 1_186_816},     # train 3 489 024
+    "siren": {"fwd": 1_053_696, "fwd_sigma": 919_552, "chain": 1_050_624, "dw": 1_053_696},    # train 3 158 016 (+2 304 sin)
+}
 PEAK_F32_MFMA = 157.3        # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0               # TB/s
-PEAK_L2_GATHER = 16.8        # TB/s: rows gathered from an L2-resident table, chip-wide lower bound (MI355X_MICROARCH.md "Indexed rows")
+PEAK_L2_GATHER = 16.8        # TB/s: rows gathered from an L2-resident table (MI355X_MICROARCH.md "Indexed rows")
+PEAK_MALL_GATHER = 8.6       # TB/s: the same from the Infinity Cache
+
+# kernel tags of the library's profiler (csrc/*.hip KernelSpan) -> (FLOP key, rocprof kernel-name fragment for the PMC file)
+KERNELS = {
+    "siren": {"train": [("siren_forward_kernel<save>", "fwd", "siren_forward_kernel<true, false, true,"),
+                        ("siren_backward_chain_kernel", "chain", "siren_backward_chain_kernel"),
+                        ("siren_dw_kernel", "dw", "siren_dw_kernel")],
+              "infer": [("siren_forward_kernel", "fwd", "siren_forward_kernel<true, false, false,"),
+                        ("siren_forward_kernel<sigma_only>", "fwd_sigma", "siren_forward_kernel<true, true, false,")]},
+    "nerf": {"train": [("nerf_forward_kernel<save>", "fwd", "nerf_forward_kernel<false, false, true>"),
+                       ("nerf_backward_chain_kernel", "chain", "nerf_backward_chain_kernel"),
+                       ("nerf_dw_kernel", "dw", "nerf_dw_kernel")],
+             "infer": [("nerf_forward_kernel", "fwd", "nerf_forward_kernel<false, false, false>"),
+                       ("nerf_forward_kernel<sigma_only>", "fwd_sigma", "nerf_forward_kernel<false, true, false>")]},
+}
+KERNELS_BF16X3 = {
+    "nerf": {"train": [("nerf_forward_bf16x3_kernel<save>", "fwd", None), ("nerf_backward_chain_bf16x3_kernel", "chain", None),
+                       ("nerf_dw_bf16x3_kernel", "dw", None)],
+             "infer": [("nerf_forward_bf16x3_kernel", "fwd", None), ("nerf_forward_bf16x3_kernel<sigma_only>", "fwd_sigma", None)]},
+    "siren": {"train": KERNELS["siren"]["train"],      # only the inference kernel of this field has a split-bf16 form
+              "infer": [("siren_forward_bf16x3_kernel", "fwd", None), ("siren_forward_bf16x3_kernel<sigma_only>", "fwd_sigma", None)]},
+}
 
 
 def parse():
@@ -51,10 +76,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
-    ap.add_argument("--batch", type=int, default=1024, help="rays per rank per step (configs[1])")
-    ap.add_argument("--field", choices=["nerf", "siren"], default="nerf",
-                    help="headline field: nerf = the reference's live 8x256 ReLU NeRF (system.py:183-190); siren = its "
-                         "FiLM-SIREN field (always reported in the `siren` object at N = 1)")
+    ap.add_argument("--batch", type=int, default=1024, help="rays per rank per step (configs[1]); --scaling weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch rays on every rank; strong: --global-batch rays split over the ranks")
+    ap.add_argument("--global-batch", type=int, default=8192, help="--scaling strong: rays per step over all ranks (configs[2])")
+    ap.add_argument("--field", choices=["siren", "nerf"], default="siren",
+                    help="headline field: siren = the FiLM-SIREN field BASELINE.json configs[1] names; nerf = the reference's "
+                         "live 8x256 ReLU NeRF (system.py:183-190; always reported in the `nerf` object at N = 1)")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="fp32",
                     help="fp32 = exact fp32 MFMA (default); bf16x3 = opt-in split-bf16 math")
     ap.add_argument("--optimizer", choices=["fused", "torch"], default="fused",
@@ -62,9 +90,11 @@ def parse():
                          "+ elementwise loss -- same arithmetic")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one joint all-reduce after the whole backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-psnr", action="store_true", help="skip the PSNR-parity check (tests/golden/g15_psnr.npz protocol)")
-    ap.add_argument("--no-opt-in", action="store_true", help="skip the extra timed loop on the opt-in split-bf16 math")
-    ap.add_argument("--no-extra", action="store_true", help="skip the infer / siren / eg3d objects")
+    ap.add_argument("--no-psnr", action="store_true", help="skip the PSNR-parity protocols (tests/golden/g15s, g19)")
+    ap.add_argument("--no-opt-in", action="store_true", help="skip the extra timed loops on the opt-in split-bf16 math")
+    ap.add_argument("--no-extra", action="store_true", help="skip the infer / nerf / eg3d objects")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not record per-kernel HIP events in the timed region (A/B of their cost; `roofline` is then null)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work in the bounded cpu_baseline sample")
     return ap.parse_args()
 
@@ -86,37 +116,45 @@ def spawn_ranks(n: int) -> int:
 
 
 # -------------------------------------------------------------------------------------------------
-# CPU baseline: the reference's torch-CPU path (restated), all physical cores
+# CPU baseline: the reference's torch-CPU path on the same workload (restated), calibrated thread count
 # -------------------------------------------------------------------------------------------------
-def cpu_baseline(mode, budget_s=12.0):
+def cpu_baseline(field, mode, budget_s=12.0):
     from nerf_siren_amd import synth
     from oracle import torch_cpu_ref as TR
-    ps = [synth.nerf_params(1, False), synth.nerf_params(2, False)]
+    if field == "siren":
+        ps = [dict(synth.siren_params(s), frequencies=synth.hash_normal((1, 2304), 10 + s),
+                   phase_shifts=synth.hash_normal((1, 2304), 20 + s)) for s in (1, 2)]
+        what = ("FiLM-SIREN fields (models/nerf.py:142-216) behind the reference's render_rays through the "
+                "forward(x, sigma_only) adapter of tools/make_psnr_golden.py --siren")
+    else:
+        ps = [synth.nerf_params(1, False), synth.nerf_params(2, False)]
+        what = "NeRF 8x256 fields"
     r = TR.timed_sample(mode, ps, lambda i: synth.blender_rays(1024, seed=123 + i),
                         lambda i: synth.hash_uniform((1024, 3), 5 + i), budget_s=budget_s, n_rays=1024)
     return {"value": r["ray_samples_per_s"], "unit": "ray-samples/s", "cores": r["threads"], "kind": "port",
             "sample": f"{r['steps']} steps of 1024 rays x (64+128) samples, {mode} step "
-                      f"({'fwd+MSE+bwd+Adam' if mode == 'train' else 'test_time render'}), the reference's torch-CPU op "
-                      f"sequence restated (oracle/torch_cpu_ref.py), {r['seconds']:.1f} s after one warm-up step",
+                      f"({'fwd+MSE+bwd+Adam' if mode == 'train' else 'test_time render'}), {what}: the reference's torch-CPU op "
+                      f"sequence restated (oracle/torch_cpu_ref.py, pinned on fixtures the imported reference produced), "
+                      f"{r['seconds']:.1f} s after one warm-up step",
             "best_step_value": r["ray_samples_per_s_best"], "cpu_model": r["cpu_model"],
             "physical_cores": r["physical_cores"], "nproc": r["nproc"], "allowed_cpus": r["allowed_cpus"],
             "cgroup_cpu_quota": r["cgroup_cpu_quota"], "thread_calibration_gemm_gflops": r["gemm_gflops"],
             "torch_parallel_info": r["parallel_info"].strip().replace("\n", "; "),
-            "anchor": "the imported reference itself on 8 threads in the build container: 0.107-0.119 M ray-samples/s "
-                      "training, 0.56-0.69 M inference (BASELINE.md section 2, oracle/torch_cpu_ref.py header)"}
+            "anchor": "the imported reference itself (NeRF field) on 8 threads in the build container: 0.107-0.119 M "
+                      "ray-samples/s training, 0.56-0.69 M inference (BASELINE.md section 2, oracle/torch_cpu_ref.py header)"}
 
 
-def psnr_check(dev):
+def psnr_check(dev, field):
     """The metric's '+ PSNR': the reference trained on a teacher scene on CPU and its validation-PSNR trajectory is a
-    committed fixture (tools/make_psnr_golden.py -> tests/golden/g15_psnr.npz); the same steps (same images, batches,
-    injected draws, initial weights, learning-rate schedule) run here on the HIP path.  Rank 0 at N = 1 only."""
+    committed fixture (tools/make_psnr_golden.py); the same steps (same images, batches, injected draws, initial weights,
+    learning-rate schedule) run here on the HIP path.  field = 'siren': g15s (the reference's SemanticNeRF as the student,
+    240 steps); 'nerf': g19 (1 500 steps of 1024 rays, 400x400 validation view).  Rank 0 at N = 1 only."""
     import numpy as np
     import torch
-    from nerf_siren_amd import Embedding, NeRF, render_rays, synth
+    from nerf_siren_amd import Embedding, NeRF, SemanticNeRF, SirenField, render_rays, synth
     from nerf_siren_amd.training import FusedAdam, FusedMSELoss
-    path = os.path.join(ROOT, "tests", "golden", "g19_psnr_long.npz")       # 1 500 steps, 400x400 validation view
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "tests", "golden", "g15_psnr.npz")        # 240 steps, 32x32
+    name = "g15s_psnr_siren.npz" if field == "siren" else "g19_psnr_long.npz"
+    path = os.path.join(ROOT, "tests", "golden", name)
     if not os.path.exists(path):
         return None
     g = dict(np.load(path))
@@ -126,8 +164,14 @@ def psnr_check(dev):
     gamma = float(g["cfg_lr_gamma"]) if "cfg_lr_gamma" in g else 1.0
     ms = []
     for seed in (11, 12):
-        m = NeRF()
-        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
+        if field == "siren":
+            sm = SemanticNeRF()
+            sm.load_state_dict({k: torch.from_numpy(v) for k, v in synth.siren_params(seed).items()})
+            m = SirenField(sm, torch.from_numpy(synth.hash_normal((1, 2304), 10 + seed)),
+                           torch.from_numpy(synth.hash_normal((1, 2304), 20 + seed)))
+        else:
+            m = NeRF()
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_params(seed, structured=False).items()})
         ms.append(m.to(dev))
     emb = [Embedding(3, 10), Embedding(3, 4)]
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)          # noqa: E731
@@ -142,7 +186,7 @@ def psnr_check(dev):
                 mse, n = 0.0, 0
                 for i in range(0, val_rays.shape[0], 1 << 15):
                     r = render_rays(ms, emb, val_rays[i:i + (1 << 15)], S, False, 0, 0, F, 1 << 15, True, False)
-                    mse += float(((r["rgb_fine"] - val_tgt[i:i + (1 << 15)]) ** 2).sum())
+                    mse += float(((r["rgb_fine"] - val_tgt[i:i + (1 << 15)]).double() ** 2).sum())
                     n += r["rgb_fine"].numel()
             psnr.append(float(-10 * np.log10(mse / n)))
         if step == steps:
@@ -157,43 +201,83 @@ def psnr_check(dev):
         if sched is not None:
             sched.step()
     ref = [float(v) for v in g["psnr"]]
-    return {"value_db": psnr[-1], "reference_db": ref[-1], "max_abs_diff_db": float(np.abs(np.array(psnr) - ref).max()),
+    return {"field": field, "value_db": psnr[-1], "reference_db": ref[-1],
+            "max_abs_diff_db": float(np.abs(np.array(psnr) - ref).max()),
             "trajectory_db": [round(v, 3) for v in psnr], "reference_trajectory_db": [round(v, 3) for v in ref],
             "protocol": f"teacher scene, {steps} Adam steps of {B} rays ({S}+{F})"
                         + (f", lr x{gamma} at steps {milestones}" if milestones else "")
-                        + f", validation every {every} steps on {val_rays.shape[0]} rays; reference = /root/reference on CPU (tests/golden/" + os.path.basename(path) + ")"}
+                        + f", validation every {every} steps on {val_rays.shape[0]} rays; reference = /root/reference on CPU "
+                          f"(tests/golden/{name})"}
 
 
-class KernelTimer:
-    """ops profiling hook: HIP events on the launch stream around the field-MLP launches of the fine pass."""
+def pmc_entry(fragment, B):
+    """Per-launch counters of a kernel from the committed rocprofv3 --pmc summary (tools/pmc_summary.py; the fine-pass
+    launch of the 1024-ray batch) -- counters cannot be collected from inside the timed run."""
+    if fragment is None or B != 1024:
+        return None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    except Exception:
+        return None
+    for k, e in pmc.items():
+        if fragment in k:
+            return e
+    return None
 
-    def __init__(self, torch):
-        self.torch = torch
-        self.ev = {}
 
-    class _Span:
-        def __init__(self, owner, key):
-            t = owner.torch
-            self.a, self.b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-            self.a.record()
-            owner.ev.setdefault(key, []).append((self.a, self.b))
+def kernel_rooflines(report, field, mode, B, table=KERNELS, peak=PEAK_F32_MFMA):
+    """report: ops.profile_report() of a timed region -> per-kernel rooflines + the dominant kernel.
+    Per kernel: `achieved` = algorithmic FLOPs of ALL its launches in the region / their summed HIP-event time (coarse and
+    fine launches together: FLOP/sample x points per coarse+fine pair / (2 x rocprof's AverageNs)); `fine_launch` = the
+    131 072-point launch alone."""
+    out, total_ms = {}, 0.0
+    for tag, fkey, frag in table[field][mode]:
+        spans = {u: v for (t, u), v in report.items() if t == tag}
+        if not spans:
+            continue
+        n = sum(c for c, _ in spans.values())
+        ms = sum(m for _, m in spans.values())
+        pts = sum(u * c for u, (c, _) in spans.items())
+        fl = FLOP[field][fkey]
+        e = {"launches": n, "avg_launch_ms": ms / n, "points_per_launch_avg": pts / n, "flop_per_point": fl,
+             "achieved": fl * pts / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "total_ms": ms}
+        e["frac"] = e["achieved"] / peak
+        big = max(spans)
+        c, m = spans[big]
+        e["fine_launch"] = {"points": big, "avg_launch_ms": m / c, "achieved": fl * big / (m / c * 1e-3) / 1e12,
+                            "frac": fl * big / (m / c * 1e-3) / 1e12 / peak, "flops_per_launch": fl * big}
+        pm = pmc_entry(frag, B)
+        if pm is not None:
+            e["fine_launch"]["traffic"] = pm.get("hbm_bytes")
+            e["fine_launch"]["mfma_busy_frac_pmc"] = pm.get("mfma_busy_frac")
+        out[tag] = e
+        total_ms += ms
+    for e in out.values():
+        e["share_of_mlp_time"] = e["total_ms"] / total_ms
+    dom = max(out, key=lambda k: out[k]["total_ms"]) if out else None
+    return out, dom
 
-        def done(self):
-            self.b.record()
 
-    def __call__(self, name, n_per_ray):
-        if n_per_ray != 128:
-            return None
-        return KernelTimer._Span(self, name)
-
-    def clear(self):
-        self.ev.clear()
-
-    def mean_ms(self, name):
-        ev = self.ev.get(name)
-        if not ev:
-            return float("nan")
-        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+def roofline_object(report, field, mode, B, steps, dt, table=KERNELS, peak=PEAK_F32_MFMA, world=1):
+    ks, dom = kernel_rooflines(report, field, mode, B, table, peak)
+    if dom is None:
+        return None
+    f = FLOP[field]
+    flop_step = (B * 192 * (f["fwd"] + f["chain"] + f["dw"])) if mode == "train" else B * (64 * f["fwd_sigma"] + 128 * f["fwd"])
+    d = ks[dom]
+    step_tf = flop_step / (dt / steps) / 1e12
+    return {"bound": "mfma", "kernel": dom + " (coarse 64 + fine 128 samples/ray launches; the MLP kernel with the largest "
+                                             "share of the step)",
+            "achieved": d["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": d["frac"],
+            "traffic": d["fine_launch"].get("traffic"), "traffic_note": "HBM bytes of the fine-pass launch, committed rocprofv3 "
+            "--pmc pass (profiles/pmc_latest.json)", "avg_launch_ms": d["avg_launch_ms"],
+            "flops_per_launch": d["flop_per_point"] * d["points_per_launch_avg"],
+            "measured": "HIP events recorded by the library on the launch stream around every field-MLP launch inside the timed "
+                        "region (nerfmi_profile_*)",
+            "kernels": ks,
+            "step": {"flop_per_step_per_gpu": flop_step, "achieved": step_tf, "frac": step_tf / peak,
+                     "note": "algorithmic FLOPs of one step / ms_per_step / peak (per GPU): everything that is not the three "
+                             "MLP kernels -- per-ray kernels, loss, Adam, packing, launch gaps, collectives -- counts as loss"}}
 
 
 def eg3d_bench(dev, steps, warmup):
@@ -254,19 +338,33 @@ def eg3d_bench(dev, steps, warmup):
         dense()
     t_d = float(np.mean(kms)) * 1e-3
     npts = pts.shape[1]
-    gather = npts * (12 + 1536 + 16) / t_d / 1e12            # R 12 B coords + 1 536 B texels / W 16 B per sample
+    alg = npts * (12 + 1536 + 16)                            # R 12 B coords + 1 536 B texels / W 16 B per sample
+    # where the texel requests were actually served: the committed rocprofv3 --pmc pass of tools/bench_eg3d.py
+    # (profiles/r03_pmc_eg3d.json, tools/pmc_eg3d.sh): TCP->TCC requests, TCC hit rate, TCC_EA read requests, FETCH_SIZE
+    served = None
+    try:
+        served = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_eg3d.json"))).get("dense_query")
+    except Exception:
+        pass
+    roof = {"bound": "l2-gather", "kernel": "triplane_kernel<1,false> (dense run_model: 12 bilinear taps x 32 ch gathered per point "
+                                            "from the 25 MB channels-last plane stack, decoder fused)",
+            "achieved": alg / t_d / 1e12, "peak": PEAK_L2_GATHER, "unit": "TB/s", "frac": alg / t_d / 1e12 / PEAK_L2_GATHER,
+            "traffic": None, "bytes_per_launch": alg, "avg_launch_ms": t_d * 1e3,
+            "note": "`achieved` = ALGORITHMIC gather bytes (before reuse between neighbouring samples) / time against the guide's "
+                    "L2-served row-gather rate (MI355X_MICROARCH.md 'Indexed rows': 16.8 TB/s from L2, 8.6 TB/s from the Infinity "
+                    "Cache); it is a reuse-inclusive figure, not a bandwidth.  `served` (when the PMC pass is committed) says where "
+                    "the requests were actually served and what the bytes-on-the-wire fractions are"}
+    if served:
+        roof["served"] = served
+        roof["traffic"] = served.get("hbm_bytes")
+        l2b = served.get("l2_request_bytes")
+        if l2b:
+            roof["l2_served"] = {"bytes_per_launch": l2b, "achieved": l2b / t_d / 1e12, "peak": PEAK_L2_GATHER, "unit": "TB/s",
+                                 "frac": l2b / t_d / 1e12 / PEAK_L2_GATHER}
     return {"workload": "configs[4]: planes (1,3,32,256,256), M=4096 rays x (64+64) samples; dense query 128^3 points",
             "forward_ms": t_f * 1e3, "forward_samples_per_s": M * 128 / t_f,
             "forward_backward_ms": t_fb * 1e3, "forward_backward_samples_per_s": M * 128 / t_fb,
-            "dense_query_ms": t_d * 1e3, "dense_points_per_s": npts / t_d,
-            "roofline": {"bound": "l2-gather", "kernel": "triplane_kernel<1,false> (dense run_model: 12 bilinear taps x 32 ch "
-                         "gathered per point from the 25 MB channels-last plane stack, decoder fused)", "achieved": gather,
-                         "peak": PEAK_L2_GATHER, "unit": "TB/s", "frac": gather / PEAK_L2_GATHER, "traffic": None,
-                         "bytes_per_launch": npts * (12 + 1536 + 16), "avg_launch_ms": t_d * 1e3,
-                         "note": "algorithmic gather bytes (before reuse between neighbouring samples); the plane stack is "
-                                 "L2 / Infinity-Cache resident, so the bound is the cache-served row-gather rate "
-                                 "(MI355X_MICROARCH.md 'Indexed rows': 16.8 TB/s from L2, 8.6 TB/s from the Infinity Cache), "
-                                 "not HBM (HBM traffic is ~60 MB per launch); the fused 32-64-4 decoder runs on the VALU"}}
+            "dense_query_ms": t_d * 1e3, "dense_points_per_s": npts / t_d, "roofline": roof}
 
 
 def main():
@@ -301,7 +399,12 @@ def main():
     from nerf_siren_amd.parallel import FlatGradAllReduce
     from nerf_siren_amd.training import FusedAdam, FusedMSELoss
 
-    B = args.batch
+    if args.scaling == "strong":
+        if args.global_batch % world:
+            raise SystemExit(f"--scaling strong: --global-batch {args.global_batch} is not divisible by {world} ranks")
+        B = args.global_batch // world
+    else:
+        B = args.batch
     nerf_siren_amd.set_math(args.math)
     emb = [Embedding(3, 10), Embedding(3, 4)]
     # a pool of batches resident in HBM before the timed region (each rank its own shard of rays)
@@ -323,30 +426,33 @@ def main():
             ms.append(m.to(dev))
         return ms
 
-    timer = KernelTimer(torch)
-    ops.set_profile_hook(timer)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step, steps, warmup):
-        """W untimed steps, then EXACTLY K steps between barrier + synchronize; MAX over ranks."""
+    def timed(step, steps, warmup, events=True):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize; MAX over ranks.  -> (seconds, kernel report)"""
         for i in range(warmup):
             step(i)
         barrier()
-        timer.clear()
+        comm_events.clear()
+        if events and not args.no_kernel_events:
+            ops.profile_start()
         t0 = time.perf_counter()
         for i in range(steps):
             step(warmup + i)
         barrier()
         dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        ops.profile_stop()
+        rep = ops.profile_report() if (events and not args.no_kernel_events) else {}
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        return float(dt.item())
+        return float(dt.item()), rep
 
-    def make_step(models, mode):
+    comm_events = []         # (before, after) HIP events around reducer.all_reduce() on the compute stream, N > 1 only
+
+    def make_step(models, mode, overlap=None):
         if mode == "infer":
             def step(i):
                 with torch.no_grad():
@@ -358,7 +464,7 @@ def main():
         else:
             opt = torch.optim.Adam([p for m in models for p in m.param_list()], lr=5e-4, eps=1e-8)
             loss_fn = None
-        reducer = FlatGradAllReduce(models, world, overlap=not args.no_overlap)
+        reducer = FlatGradAllReduce(models, world, overlap=(not args.no_overlap) if overlap is None else overlap)
 
         def step(i):
             res = render_rays(models, emb, rays_pool[i % n_pool], 64, False, 1.0, 1.0, 64, 1024 * 32, True, False)
@@ -369,127 +475,134 @@ def main():
                 loss = ((res["rgb_coarse"] - t) ** 2).mean() + ((res["rgb_fine"] - t) ** 2).mean()   # losses.py:15-20
             opt.zero_grad(set_to_none=True)
             loss.backward()
+            if world > 1:
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record()
             if loss_fn is not None:
                 reducer.all_reduce(average=False)               # the 1/world factor rides in the Adam kernel
-                opt.step(grad_scale=1.0 / world)
             else:
                 reducer.all_reduce()
+            if world > 1:
+                eb.record()
+                comm_events.append((ea, eb))
+            if loss_fn is not None:
+                opt.step(grad_scale=1.0 / world)
+            else:
                 opt.step()
         return step
 
-    siren = args.field == "siren"
-    train = args.mode == "train"
-    models = make_models(args.field)
-    step = make_step(models, args.mode)
-    dt = timed(step, args.steps, args.warmup)
+    field, mode = args.field, args.mode
+    train = mode == "train"
+    table = KERNELS if args.math == "fp32" else KERNELS_BF16X3
+    peak = PEAK_F32_MFMA if args.math == "fp32" else 2500.0 / 6.0    # split-bf16: six bf16 MFMAs per fp32-equivalent product
+    models = make_models(field)
+    step = make_step(models, mode)
+    dt, rep = timed(step, args.steps, args.warmup)
+    roof = roofline_object(rep, field, mode, B, args.steps, dt, table, peak) if rep else None
 
-    if siren:
-        kname = "siren_forward_rays_train" if train else ("siren_forward_rays_fast" if args.math == "bf16x3" else "siren_forward_rays")
-    else:
-        kname = "nerf_forward_rays_fast" if args.math == "bf16x3" else "nerf_forward_rays"
-    kern_ms = timer.mean_ms(kname)
+    def comm_ms():
+        torch.cuda.synchronize()
+        v = [a.elapsed_time(b) for a, b in comm_events]
+        comm_events.clear()
+        return sum(v) / len(v) if v else None
 
-    # The same K steps once more on the OPT-IN split-bf16 math (fp32-level accuracy on the bf16 matrix cores, same parity
-    # tests) -- reported beside the headline, never as `value`.
-    opt_in = None
-    if args.math == "fp32" and not siren and not args.no_opt_in:
-        nerf_siren_amd.set_math("bf16x3")
-        dt2 = timed(step, args.steps, args.warmup)
-        nerf_siren_amd.set_math("fp32")
-        opt_in = {"math": "bf16x3 (exact 3-way bf16 split of both operands, 6 bf16 MFMA per product, fp32 accumulate)",
-                  "value": world * B * 192 * args.steps / dt2, "unit": "ray-samples/s", "ms_per_step": dt2 / args.steps * 1e3}
-
-    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc summary (tools/pmc_summary.py);
-    # counters cannot be collected from inside the timed run
-    def pmc_traffic(want):
+    # N > 1: what the ranks saw, and the collective alone vs its exposed part under overlap (a side run with the other setting)
+    dist_info = comm = None
+    if world > 1 and train:
+        ms_main = comm_ms()
+        other = bool(args.no_overlap)                            # the main run's overlap flag was `not args.no_overlap`
+        ks = max(5, args.steps // 2)
+        d_side, _ = timed(make_step(models, mode, overlap=other), ks, 2, events=False)
+        ms_side = comm_ms()
+        over_ms, plain_ms = (ms_side, ms_main) if other else (ms_main, ms_side)
+        over_step, plain_step = (d_side / ks * 1e3, dt / args.steps * 1e3) if other else (dt / args.steps * 1e3, d_side / ks * 1e3)
+        nbytes = sum(m.grad_numel for m in models) * 4
+        comm = {"allreduce_bytes_per_step": nbytes,
+                "allreduce_ms_no_overlap": plain_ms, "exposed_ms_with_overlap": over_ms,
+                "ms_per_step_no_overlap": plain_step, "ms_per_step_with_overlap": over_step,
+                "how": "HIP events on the compute stream around FlatGradAllReduce.all_reduce(): without overlap that is the one "
+                       "joint all-reduce of both fields' gradients; with overlap the fine field's slice was put on the wire "
+                       "under the coarse field's backward and what remains is the wait for it + the coarse slice's all-reduce"}
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device": torch.cuda.get_device_name(dev),
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "pci_domain_id": getattr(props, "pci_domain_id", None),
+                "uuid": str(getattr(props, "uuid", "")), "rays_per_step": B, "pid": os.getpid()}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            for k, e in pmc.items():
-                if want in k and "hbm_bytes" in e and B == 1024:
-                    return e["hbm_bytes"]
+            nccl_v = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
-            pass
-        return None
-    if siren:
-        traffic = pmc_traffic("siren_forward_kernel<true, false, true," if train else "siren_forward_kernel<true, false, false,")
-    else:
-        traffic = pmc_traffic("nerf_forward_kernel<false, false, true>" if train else "nerf_forward_kernel<false, false, false>")
-    flops_per_launch = B * 128 * (FLOP_SIREN if siren else FLOP_FULL)
-    achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
-    # exact fp32 MFMA: 157.3 TF dense; split-bf16 (six bf16 MFMAs per fp32-equivalent product): 2500/6
-    peak = PEAK_F32_MFMA if args.math == "fp32" else 2500.0 / 6.0
+            nccl_v = None
+        dist_info = {"world_size_seen_by_torch_distributed": dist.get_world_size(), "backend": dist.get_backend(),
+                     "rccl_version": nccl_v, "env_world_size": world, "ranks": allr,
+                     "distinct_devices": len({(r["pci_domain_id"], r["pci_bus_id"], r["device_index"]) for r in allr})}
 
     extra = {}
     if world == 1 and not args.no_extra and args.math == "fp32":
         ks, kw = max(5, args.steps // 2), max(2, args.warmup // 2)
-        if not siren:
-            # the same field at test time (eval.py:85-96)
-            st = make_step(models, "infer") if train else make_step(make_models("nerf"), "train")
-            d2 = timed(st, ks, kw)
-            k2 = timer.mean_ms("nerf_forward_rays")
-            extra["infer" if train else "train"] = {
-                "ms_per_step": d2 / ks * 1e3, "value": B * 192 * ks / d2, "unit": "ray-samples/s",
-                "roofline": {"bound": "mfma", "kernel": "nerf_forward_kernel (fine MLP, 128 samples/ray)",
-                             "achieved": B * 128 * FLOP_FULL / (k2 * 1e-3) / 1e12, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                             "frac": B * 128 * FLOP_FULL / (k2 * 1e-3) / 1e12 / PEAK_F32_MFMA, "avg_launch_ms": k2}}
-            # the FiLM-SIREN field of configs[1] (models/nerf.py:142-216) behind the same render_rays: training + inference
-            sm = make_models("siren")
-            d_t = timed(make_step(sm, "train"), ks, kw)
-            k_t = timer.mean_ms("siren_forward_rays_train")
-            d_i = timed(make_step(sm, "infer"), ks, kw)
-            k_i = timer.mean_ms("siren_forward_rays")
-            nerf_siren_amd.set_math("bf16x3")                     # the opt-in split-bf16 inference kernel of the same field
-            d_f = timed(make_step(sm, "infer"), ks, kw)
+
+        def leg(fld, md, ms=None, tbl=KERNELS, pk=PEAK_F32_MFMA):
+            ms = ms if ms is not None else make_models(fld)
+            d, r = timed(make_step(ms, md), ks, kw)
+            return {"ms_per_step": d / ks * 1e3, "value": B * 192 * ks / d, "unit": "ray-samples/s",
+                    "roofline": roofline_object(r, fld, md, B, ks, d, tbl, pk) if r else None}
+        other_mode = "infer" if train else "train"
+        extra[other_mode] = leg(field, other_mode, models)       # the same field at test time (eval.py:85-96) / in training
+        other_field = "nerf" if field == "siren" else "siren"
+        om = make_models(other_field)
+        extra[other_field] = {
+            "workload": "configs[1] with " + ("the reference's live ReLU NeRF 8x256 (system.py:181-192, 595 844 parameters)"
+                                              if other_field == "nerf" else "the FiLM-SIREN field (9 FiLM layers x 256, 529 156 "
+                                              "parameters)") + f" coarse+fine, batch_size={B}",
+            "train": leg(other_field, "train", om), "infer": leg(other_field, "infer", om)}
+        if not args.no_opt_in:
+            # the same steps on the OPT-IN split-bf16 math (fp32-level accuracy on the bf16 matrix cores, same parity tests;
+            # DESIGN.md section 4) -- reported beside the headline, never as `value`
+            nerf_siren_amd.set_math("bf16x3")
+            nm = om if other_field == "nerf" else models
+            sm = models if field == "siren" else om
+            extra["opt_in"] = {
+                "math": "bf16x3 (exact 3-way bf16 split of both operands, 6 bf16 MFMA per product, fp32 accumulate)",
+                "nerf_train": leg("nerf", "train", nm, KERNELS_BF16X3, 2500.0 / 6.0),
+                "nerf_infer": leg("nerf", "infer", nm, KERNELS_BF16X3, 2500.0 / 6.0),
+                "siren_infer": leg("siren", "infer", sm, KERNELS_BF16X3, 2500.0 / 6.0)}
             nerf_siren_amd.set_math("fp32")
-            fl = B * 128 * FLOP_SIREN
-            extra["siren"] = {
-                "workload": f"configs[1] with the FiLM-SIREN field (9 FiLM layers x 256, 529 156 parameters) coarse+fine, "
-                            f"batch_size={B}",
-                "train_ms_per_step": d_t / ks * 1e3, "train_value": B * 192 * ks / d_t,
-                "infer_ms_per_step": d_i / ks * 1e3, "infer_value": B * 192 * ks / d_i, "unit": "ray-samples/s",
-                "opt_in_infer": {"math": "bf16x3", "ms_per_step": d_f / ks * 1e3, "value": B * 192 * ks / d_f},
-                "roofline": {"bound": "mfma", "kernel": "siren_forward_kernel<true,false,false> (fine pass, 128 samples/ray, "
-                             "inference)", "achieved": fl / (k_i * 1e-3) / 1e12, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                             "frac": fl / (k_i * 1e-3) / 1e12 / PEAK_F32_MFMA, "flops_per_launch": fl, "avg_launch_ms": k_i,
-                             "traffic": pmc_traffic("siren_forward_kernel<true, false, false,")},
-                "roofline_train_forward": {"bound": "mfma", "kernel": "siren_forward_kernel<true,false,true> (fine pass, saves "
-                                           "activations)", "achieved": fl / (k_t * 1e-3) / 1e12, "peak": PEAK_F32_MFMA,
-                                           "unit": "TFLOP/s", "frac": fl / (k_t * 1e-3) / 1e12 / PEAK_F32_MFMA,
-                                           "avg_launch_ms": k_t,
-                                           "traffic": pmc_traffic("siren_forward_kernel<true, false, true,")}}
-            del sm
-        ops.set_profile_hook(None)
+        del om
         extra["eg3d"] = eg3d_bench(dev, ks, kw)
 
     if rank == 0:
         total_samples = world * B * 192 * args.steps
+        fname = "FiLM-SIREN 9x256 (models/nerf.py:142-216)" if field == "siren" else "NeRF 8x256 (models/nerf.py:41-124)"
         out = {
             "metric": "ray-samples/sec, Blender-lego 400x400 synthetic rays, 64c+64f"
                       + (" (training step)" if train else " (inference, test_time)"),
             "value": total_samples / dt, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.math == "fp32" else "f32 (3xbf16 split, 6 bf16 MFMA per product)", "data": "synthetic",
-            "config": {"workload": f"configs[1]: Blender-lego 400x400 rays, N_samples=64 N_importance=64, "
-                                   f"batch_size={B} rays/GPU, {'FiLM-SIREN 9x256' if siren else 'NeRF 8x256'} coarse+fine, "
-                                   f"mode={args.mode}",
-                       "rays_per_gpu": B, "samples_per_ray": 192, "mode": args.mode,
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32" if args.math == "fp32" else "f32 (3xbf16 split, 6 bf16 MFMA per product)", "data": "synthetic",
+            "config": {"workload": f"configs[1]: Blender-lego 400x400 rays, N_samples=64 N_importance=64, SIREN-MLP = {fname} "
+                                   f"coarse+fine, batch_size={B} rays/GPU, mode={mode}"
+                       if field == "siren" else
+                       f"configs[1] shape (Blender-lego 400x400 rays, 64+64, batch_size={B} rays/GPU) with the reference's live "
+                       f"field {fname} coarse+fine, mode={mode}",
+                       "field": field, "rays_per_gpu": B, "global_rays_per_step": B * world, "samples_per_ray": 192, "mode": mode,
                        "parallelism": (f"dp{world}, one rank per GPU, {'fine-model all-reduce overlapped with the coarse backward' if not args.no_overlap else 'one joint all-reduce'}"
                                        if world > 1 else "single")},
             "rays_per_s": world * B * args.steps / dt,
-            "roofline": {"bound": "mfma", "kernel": ("siren_forward_kernel" if siren else ("nerf_forward_kernel" if args.math == "fp32" else
-                                                                          "nerf_forward_bf16x3_kernel"))
-                                   + " (fine MLP, 128 samples/ray" + (", saves activations)" if train else ")"),
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "flops_per_launch": flops_per_launch, "avg_launch_ms": kern_ms},
+            "roofline": roof,
         }
+        if dist_info is not None:
+            out["dist"] = dist_info
+        if comm is not None:
+            out["comm"] = comm
         out.update(extra)
-        if opt_in is not None:
-            out["opt_in"] = opt_in
-        if world == 1 and train and not siren and not args.no_psnr:
-            out["psnr"] = psnr_check(dev)
-        if world == 1 and not args.no_cpu_baseline and not siren:
-            out["cpu_baseline"] = cpu_baseline(args.mode, budget_s=args.cpu_seconds)
+        if world == 1 and train and not args.no_psnr and args.math == "fp32":
+            out["psnr"] = psnr_check(dev, field)
+            if not args.no_extra:
+                out["psnr_" + ("nerf" if field == "siren" else "siren")] = psnr_check(dev, "nerf" if field == "siren" else "siren")
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(field, mode, budget_s=args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

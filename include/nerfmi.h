@@ -234,6 +234,32 @@ int nerfmi_importance_resample(const float *z_coarse, const float *weights_coars
                                int n_samples, int n_importance, float *z_new_out, float *z_fine_out,
                                nerfmi_stream_t stream);
 
+/* ---- a1: one call for a whole render_rays() pass under no_grad -- models/rendering.py:70-262 as eval.py:85-96 and the
+ * validation loop system.py:243-256 call it.  Enqueues on `stream`, out of ONE caller-provided workspace
+ * (nerfmi_render_rays_workspace_floats floats): sampler -> field(coarse; sigma-only when test_time) -> compositor ->
+ * importance resampling -> field(fine) -> compositor.  field_kind 0 = NeRF (packed_* from nerfmi_nerf_pack), 1 = FiLM-SIREN
+ * (packed_* from nerfmi_siren_pack; cond_* = one conditioning row each, [frequencies 2304 | phase_shifts 2304]).  Random
+ * draws (perturb > 0: jitter and u; noise_std != 0: density noise) come from the Philox streams (seed, offset) exactly as in
+ * the *_philox entry points, so the result is bit-identical to the call-by-call sequence with the same key.
+ * Outputs as in the reference's result dict: rgb_* (n_rays,3), depth_*, opacity_* (n_rays); with test_time the coarse
+ * rgb/depth are not produced (rendering.py:227-231) and may be NULL; n_importance == 0 skips the fine pass. */
+size_t nerfmi_render_rays_workspace_floats(int n_rays, int n_samples, int n_importance, int test_time);
+int nerfmi_render_rays_fused(int field_kind, const float *packed_coarse, const float *packed_fine,
+                             const float *cond_coarse, const float *cond_fine, const float *rays, int n_rays,
+                             int n_samples, int n_importance, int use_disp, float perturb, float noise_std,
+                             int white_back, int test_time, uint64_t seed, uint64_t offset, float *workspace,
+                             float *rgb_coarse, float *depth_coarse, float *opacity_coarse, float *rgb_fine,
+                             float *depth_fine, float *opacity_fine, nerfmi_stream_t stream);
+
+/* ---- measurement aid: HIP events recorded on the launch stream around the field-MLP kernels (forward, dX chain, dW
+ * GEMM, slab reduction) between nerfmi_profile_start() and nerfmi_profile_stop().  nerfmi_profile_report waits for the
+ * recorded spans and writes one line per (kernel tag, units per launch): "<tag>\t<points>\t<launches>\t<total ms>\n";
+ * it returns the length of the full report (call with cap 0 to size the buffer).  Process-wide, mutex-guarded; off by
+ * default (the only global state of the library besides the thread-local error string). */
+int nerfmi_profile_start(void);
+int nerfmi_profile_stop(void);
+int64_t nerfmi_profile_report(char *buf, size_t cap);
+
 /* ==== the step before the path: ray generation on the device ========================
  * datasets/ray_utils.py:5-24 get_ray_directions(H, W, focal) -> dirs_out (H, W, 3): ((i-W/2)/focal, -(j-H/2)/focal, -1),
  * i = column, j = row (kornia.create_meshgrid(H, W, normalized_coordinates=False)). */

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 # experiment builds (tools/exp_*.py): NERFMI_LIB_OUT=<path> writes another library, NERFMI_SOURCES="a.hip b.hip" restricts
 # the translation units, NERFMI_EXTRA_FLAGS="-D..." adds switches (objects of a different flag set get their own directory)
 LIB = os.environ.get("NERFMI_LIB_OUT") or os.path.join(HERE, "lib", "libnerfmi.so")
-SOURCES = ["rays.hip", "mlp.hip", "mlp_bwd.hip", "siren.hip", "siren_bwd.hip", "eg3d.hip", "eg3d_bwd.hip", "mlp_bf16x3.hip", "train_step.hip", "raygen.hip"]
+SOURCES = ["rays.hip", "mlp.hip", "mlp_bwd.hip", "siren.hip", "siren_bwd.hip", "eg3d.hip", "eg3d_bwd.hip", "mlp_bf16x3.hip", "train_step.hip", "raygen.hip", "render.hip"]
 # -ffp-contract=off: the per-ray kernels reproduce torch's op-by-op fp32 rounding
 # (oracle/nerf_oracle.py); fused multiply-adds are written explicitly where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

@@ -27,6 +27,18 @@ inline int check_launch(const char *what) {
     return NERFMI_OK;
 }
 
+// Kernel-span profiler (render.hip): HIP events on the launch stream around a kernel, collected while
+// nerfmi_profile_start() ... nerfmi_profile_stop() is active (bench.py's per-kernel rooflines); one branch when off.
+extern bool g_profile_on;
+int profile_begin(const char *tag, int64_t units, hipStream_t st);
+void profile_end(int idx, hipStream_t st);
+struct KernelSpan {
+    int idx;
+    hipStream_t st;
+    KernelSpan(const char *tag, int64_t units, hipStream_t s) : idx(g_profile_on ? profile_begin(tag, units, s) : -1), st(s) {}
+    ~KernelSpan() { if (idx >= 0) profile_end(idx, st); }
+};
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's instance of the kernel, so "done" is
 // tracked per device (a per-thread flag would skip the call on a second GPU driven from the same thread).  Racing
 // threads at worst both set the same value.

@@ -315,6 +315,8 @@ int nerfmi_nerf_forward_rays(const float *packed, const float *rays, const float
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     const int64_t ld = pad_points(n_points);
     hipStream_t st = (hipStream_t)stream;
+    KernelSpan span(sigma_only ? "nerf_forward_kernel<sigma_only>" : (saved ? "nerf_forward_kernel<save>" : "nerf_forward_kernel"),
+                    n_points, st);
     if (sigma_only)
         hipLaunchKernelGGL((nerf_forward_kernel<false, true, false>), grid, block, 0, st, packed, rays, z, nullptr,
                            n_points, n_per_ray, out, nullptr, ld);

@@ -275,6 +275,8 @@ int nerfmi_nerf_forward_rays_fast(const float *packed, const void *fast, const f
     const int64_t ld = waves * 32;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    KernelSpan span(sigma_only ? "nerf_forward_bf16x3_kernel<sigma_only>" : (saved ? "nerf_forward_bf16x3_kernel<save>"
+                                                                                      : "nerf_forward_bf16x3_kernel"), n_points, st);
     if (sigma_only)
         hipLaunchKernelGGL((nerf_forward_bf16x3_kernel<true, false>), grid, block, FLDS_BYTES, st, packed,
                            (const __bf16 *)fast, rays, z, n_points, n_per_ray, out, nullptr, ld);

@@ -565,17 +565,26 @@ static int backward_impl(const char *who, const float *packed, const void *fast,
         }
         lds_attr_set.mark(attr_dev);
     }
-    if (fast)
-        hipLaunchKernelGGL(nerf_backward_chain_bf16x3_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), FLDS_BYTES, st,
-                           packed, (const __bf16 *)fast, saved, grad_out, n_points, ld, work);
-    else
-        hipLaunchKernelGGL(nerf_backward_chain_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
-                           grad_out, n_points, ld, work);
-    if (fast)
-        hipLaunchKernelGGL(nerf_dw_bf16x3_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
-    else
-        hipLaunchKernelGGL(nerf_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
-    hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(128, P.n_tasks), dim3(256), 0, st, P, partial, G);
+    {
+        KernelSpan span(fast ? "nerf_backward_chain_bf16x3_kernel" : "nerf_backward_chain_kernel", n_points, st);
+        if (fast)
+            hipLaunchKernelGGL(nerf_backward_chain_bf16x3_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), FLDS_BYTES, st,
+                               packed, (const __bf16 *)fast, saved, grad_out, n_points, ld, work);
+        else
+            hipLaunchKernelGGL(nerf_backward_chain_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
+                               grad_out, n_points, ld, work);
+    }
+    {
+        KernelSpan span(fast ? "nerf_dw_bf16x3_kernel" : "nerf_dw_kernel", n_points, st);
+        if (fast)
+            hipLaunchKernelGGL(nerf_dw_bf16x3_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
+        else
+            hipLaunchKernelGGL(nerf_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
+    }
+    {
+        KernelSpan span("dw_reduce_kernel<nerf>", n_points, st);
+        hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(128, P.n_tasks), dim3(256), 0, st, P, partial, G);
+    }
     return check_launch(who);
 }
 

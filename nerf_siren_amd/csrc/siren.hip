@@ -106,24 +106,12 @@ siren_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__re
         const int r = 2 * pr;
         const int u = 256 * layer + 32 * kb + 8 * (r >> 2) + (r & 3);
         const float2 f = *reinterpret_cast<const float2 *>(fq + u), s = *reinterpret_cast<const float2 *>(ph + u);
-        // the hardware sine on pre-divided FiLM constants, as in the fp32 kernels (siren_core.h): ~3 issue slots per value
-        // where rounds 1-2 spent 13 on the polynomial -- this hook runs between the consuming layer's XDL MFMAs, which
-        // hide about five vector instructions each
-        // (written as single-value asm: left to the compiler these become v_pk_fma_f32 / v_pk_mul_f32, and packed-fp32
-        // instructions do not overlap with the bf16 MFMAs, bf16x3_core.h split_pair; their results feed v_sin_f32, never an
-        // MFMA operand, so the inline-asm hazard of bf16x3_core.h does not arise)
-        float fr0, fr1, p0, p1, t0, t1;
-        const float k15 = 15.0f, k30 = 30.0f, kinv = INV_2PI;
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(fr0) : "v"(f.x), "v"(k15), "v"(k30));
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(fr1) : "v"(f.y), "v"(k15), "v"(k30));
-        asm("v_mul_f32 %0, %1, %2" : "=v"(fr0) : "v"(fr0), "v"(kinv));
-        asm("v_mul_f32 %0, %1, %2" : "=v"(fr1) : "v"(fr1), "v"(kinv));
-        asm("v_mul_f32 %0, %1, %2" : "=v"(p0) : "v"(s.x), "v"(kinv));
-        asm("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(s.y), "v"(kinv));
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(fr0), "v"(x0), "v"(p0));
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(fr1), "v"(x1), "v"(p1));
-        x0 = __builtin_amdgcn_sinf(t0);
-        x1 = __builtin_amdgcn_sinf(t1);
+        // The degree-9 polynomial sin_pi here, NOT the hardware sine of the fp32 kernels (siren_core.h): this hook runs between
+        // the consuming layer's XDL MFMAs, which hide ~5 plain vector instructions each but not the transcendental unit --
+        // measured (round 3, same box): v_sin_f32 in this hook 1.08 ms per fine pass, the 13-instruction polynomial 0.90 ms.
+        unsigned jb0, jb1;
+        x0 = sin_pi(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.x, 15.0f), 30.0f), x0), s.x), jb0);
+        x1 = sin_pi(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.y, 15.0f), 30.0f), x1), s.y), jb1);
     };
     auto film_hook = [&film](int layer) {
         return [&film, layer](int kb, int pr, float &x0, float &x1) { film(layer, kb, pr, x0, x1); };
@@ -223,6 +211,7 @@ int nerfmi_siren_forward_rays(const float *packed, const float *rays, const floa
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool one_cond = rays_per_cond >= n_rays;
+    KernelSpan span(sigma_only ? "siren_forward_kernel<sigma_only>" : "siren_forward_kernel", n_points, st);
     if (sigma_only)
         SIREN_FORWARD_LAUNCH(true, true, false, grid, block, 0, st, packed, rays, z, nullptr, nullptr,
                            frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out, nullptr, (int64_t)0);
@@ -264,6 +253,7 @@ int nerfmi_siren_forward_rays_fast(const float *packed, const void *fast, const 
     const int64_t waves = (n_points + 31) / 32;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    KernelSpan span(sigma_only ? "siren_forward_bf16x3_kernel<sigma_only>" : "siren_forward_bf16x3_kernel", n_points, st);
     if (sigma_only)
         hipLaunchKernelGGL((siren_forward_bf16x3_kernel<true>), grid, block, FLDS_BYTES, st, packed, (const __bf16 *)fast,
                            rays, z, frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out);

@@ -354,6 +354,7 @@ int nerfmi_siren_forward_rays_train(const float *packed, const float *rays, cons
     NERFMI_REQUIRE(packed && rays && z && frequencies && phase_shifts && out && saved, "siren_forward_rays_train: null pointer");
     const int64_t waves = (n_points + 31) / 32;
     const bool one_cond = rays_per_cond >= n_rays;
+    KernelSpan span("siren_forward_kernel<save>", n_points, (hipStream_t)stream);
     SIREN_FORWARD_LAUNCH(true, false, true, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, packed, rays, z, nullptr, nullptr, frequencies, phase_shifts, n_points,
                        n_per_ray, rays_per_cond * n_per_ray, out, saved, siren_pad_points(n_points));
@@ -412,15 +413,24 @@ static int siren_backward_impl(const char *who, const float *packed, const float
         }
         attr_set.mark(attr_dev);
     }
-    if (one_cond)       // the workspace images hold G = dZ / fr; the reduction scales the rows (header of this file)
-        hipLaunchKernelGGL(siren_backward_chain_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed, saved,
-                           grad_out, frequencies, n_points, points_per_cond, ld, work);
-    else
-        hipLaunchKernelGGL(siren_backward_chain_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed,
-                           saved, grad_out, frequencies, n_points, points_per_cond, ld, work);
-    hipLaunchKernelGGL(siren_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
-    hipLaunchKernelGGL(siren_dw_reduce_kernel, dim3(256, SIREN_GROUPS), dim3(256), 0, st, P, partial, G, packed, frequencies,
-                       one_cond ? 1 : 0, grad_frequencies, grad_phase_shifts);
+    {
+        KernelSpan span("siren_backward_chain_kernel", n_points, st);
+        if (one_cond)   // the workspace images hold G = dZ / fr; the reduction scales the rows (header of this file)
+            hipLaunchKernelGGL(siren_backward_chain_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed,
+                               saved, grad_out, frequencies, n_points, points_per_cond, ld, work);
+        else
+            hipLaunchKernelGGL(siren_backward_chain_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed,
+                               saved, grad_out, frequencies, n_points, points_per_cond, ld, work);
+    }
+    {
+        KernelSpan span("siren_dw_kernel", n_points, st);
+        hipLaunchKernelGGL(siren_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
+    }
+    {
+        KernelSpan span("siren_dw_reduce_kernel", n_points, st);
+        hipLaunchKernelGGL(siren_dw_reduce_kernel, dim3(256, SIREN_GROUPS), dim3(256), 0, st, P, partial, G, packed, frequencies,
+                           one_cond ? 1 : 0, grad_frequencies, grad_phase_shifts);
+    }
     return check_launch(who);
 }
 

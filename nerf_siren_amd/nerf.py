@@ -253,6 +253,15 @@ class SirenField(nn.Module):
     def param_list(self):
         return self.model.param_list()
 
+    def cond_rows(self):
+        """(2, 2304) [frequencies; phase_shifts] in one buffer (what nerfmi_render_rays_fused takes), rebuilt when either
+        row changed."""
+        key = (self.frequencies.data_ptr(), self.frequencies._version, self.phase_shifts.data_ptr(), self.phase_shifts._version)
+        if getattr(self, "_cond_key", None) != key:
+            self._cond_rows = torch.cat([self.frequencies.detach().reshape(1, -1), self.phase_shifts.detach().reshape(1, -1)]).contiguous()
+            self._cond_key = key
+        return self._cond_rows
+
     def cond_param_list(self):
         """[frequencies, phase_shifts] when either is trainable (`.requires_grad_(True)`), else []: render_rays then
         differentiates through the FiLM conditioning as the reference's autograd does (nerf.py:147-151)."""

@@ -62,15 +62,65 @@ class _Span:
         return False
 
 
-def version() -> int:
-    return _lib.lib().nerfmi_version()
-
-
-# --------------------------------------------------------------------------- a2
 def _u64(v):
     return int(v) & (2 ** 64 - 1)
 
 
+def version() -> int:
+    return _lib.lib().nerfmi_version()
+
+
+# Kernel-span profiler of the library (csrc/render.hip): HIP events on the launch stream around every field-MLP kernel.
+def profile_start():
+    check(_lib.lib().nerfmi_profile_start(), "profile_start")
+
+
+def profile_stop():
+    check(_lib.lib().nerfmi_profile_stop(), "profile_stop")
+
+
+def profile_report():
+    """-> {(kernel tag, points per launch): (launches, total ms)} of the spans recorded since profile_start();
+    waits for them."""
+    n = _lib.lib().nerfmi_profile_report(None, 0)
+    buf = C.create_string_buffer(int(n) + 1)
+    _lib.lib().nerfmi_profile_report(buf, int(n) + 1)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        tag, units, cnt, ms = line.split("\t")
+        out[(tag, int(units))] = (int(cnt), float(ms))
+    return out
+
+
+# --------------------------------------------------------------------------- a1 (one call per no_grad pass)
+def render_rays_fused(field_kind, packed_coarse, packed_fine, cond_coarse, cond_fine, rays, n_samples, n_importance,
+                      use_disp, perturb, noise_std, white_back, test_time, draw_key):
+    """nerfmi_render_rays_fused: the whole no_grad pass of render_rays from ONE C-ABI call -> the reference's result dict.
+    field_kind 0: NeRF packed blobs; 1: FiLM-SIREN packed blobs + cond_* = (2, 2304) [frequencies; phase_shifts]."""
+    rays = _req(rays, "rays", (None, 8))
+    n, dev = rays.shape[0], rays.device
+    S, F = int(n_samples), int(n_importance)
+    ws = torch.empty(_lib.lib().nerfmi_render_rays_workspace_floats(n, S, F, int(bool(test_time))), device=dev,
+                     dtype=torch.float32)
+    # outputs out of one allocation: [rgb_c 3 | depth_c | opacity_c | rgb_f 3 | depth_f | opacity_f] x n
+    o = torch.empty((10, n), device=dev, dtype=torch.float32)
+    rgb_c, depth_c, op_c = o[0:3].view(-1).view(n, 3), o[3], o[4]
+    rgb_f, depth_f, op_f = o[5:8].view(-1).view(n, 3), o[8], o[9]
+    seed, offset = draw_key if draw_key is not None else (0, 0)
+    check(_lib.lib().nerfmi_render_rays_fused(int(field_kind), ptr(packed_coarse), ptr(packed_fine), ptr(cond_coarse),
+                                              ptr(cond_fine), ptr(rays), n, S, F, int(bool(use_disp)), float(perturb),
+                                              float(noise_std), int(bool(white_back)), int(bool(test_time)), _u64(seed),
+                                              _u64(offset), ptr(ws), None if test_time else ptr(rgb_c),
+                                              None if test_time else ptr(depth_c), ptr(op_c), ptr(rgb_f) if F else None,
+                                              ptr(depth_f) if F else None, ptr(op_f) if F else None, _stream(rays)),
+          "render_rays_fused")
+    result = {"opacity_coarse": op_c} if test_time else {"rgb_coarse": rgb_c, "depth_coarse": depth_c, "opacity_coarse": op_c}
+    if F:
+        result.update(rgb_fine=rgb_f, depth_fine=depth_f, opacity_fine=op_f)
+    return result
+
+
+# --------------------------------------------------------------------------- a2
 def sample_stratified(rays, n_samples, use_disp=False, perturb=0.0, perturb_rand=None, philox=None):
     """philox = (seed, offset): draw the jitter in the kernel (segment 0 of that stream) instead of reading perturb_rand."""
     rays = _req(rays, "rays", (None, 8))

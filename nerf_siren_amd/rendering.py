@@ -233,6 +233,20 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     # other draw is made INSIDE the consuming kernel from one Philox key per call (seed and offset of torch's CUDA
     # generator of the device, which the call advances: ops.next_draw_key) -- no aten distribution launches, no tensors of draws.
     draw_key = ops.next_draw_key(dev) if (perturb != 0 or noise_std != 0) else None
+
+    # no_grad pass with nothing injected and nothing asked back: the whole sequence from ONE C-ABI call
+    # (nerfmi_render_rays_fused: same kernels, same Philox key -> bit-identical to the call-by-call sequence below)
+    if not train and rng is None and aux is None and _MATH == "fp32" and N > 0 and perturb >= 0:
+        ms = list(models[:2 if F > 0 else 1])
+        kinds = {("siren" if hasattr(m, "field_rays") else "nerf") for m in ms}
+        if len(kinds) == 1 and (F == 0 or len(models) > 1):
+            siren = kinds == {"siren"}
+            packed = [(m.model if siren else m).packed() for m in ms]
+            conds = [m.cond_rows() for m in ms] if siren else [None]
+            return ops.render_rays_fused(int(siren), packed[0], packed[-1] if F > 0 else None, conds[0],
+                                         conds[-1] if F > 0 else None, rays, S, F, use_disp, float(perturb),
+                                         float(noise_std), white_back, test_time, draw_key)
+
     pr = _rng(rng, "perturb_rand", (N, S)) if perturb > 0 else None
     z = ops.sample_stratified(rays, S, use_disp, float(perturb), pr, philox=draw_key)
 

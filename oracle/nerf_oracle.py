@@ -101,29 +101,38 @@ def nerf_forward(p: dict, x: np.ndarray, sigma_only: bool = False, keep: bool = 
     in_xyz = x[:, :63]
     h = in_xyz
     acts = []                      # inputs of each xyz_encoding layer
+    pres = []                      # pre-activations (tests: which units sit on the ReLU kink)
     for i in range(8):
         if i == 4:                 # skips=[4], nerf.py:108-109
             h = np.concatenate([in_xyz, h], -1)
         acts.append(h)
-        h = np.maximum(_lin(p, f"xyz_encoding_{i+1}.0", h), F32(0))
+        pre = _lin(p, f"xyz_encoding_{i+1}.0", h)
+        pres.append(pre)
+        h = np.maximum(pre, F32(0))
     sigma = _lin(p, "sigma", h)
     if sigma_only:
-        return (sigma, dict(acts=acts, h8=h)) if keep else sigma
+        return (sigma, dict(acts=acts, h8=h, pres=pres)) if keep else sigma
     final = _lin(p, "xyz_encoding_final", h)
     dir_in = np.concatenate([final, x[:, 63:90]], -1)       # nerf.py:118
-    dir_h = np.maximum(_lin(p, "dir_encoding.0", dir_in), F32(0))
+    dir_pre = _lin(p, "dir_encoding.0", dir_in)
+    dir_h = np.maximum(dir_pre, F32(0))
     rgb_pre = _lin(p, "rgb.0", dir_h)
     rgb = (F32(1) / (F32(1) + np.exp(-rgb_pre.astype(F64)))).astype(F32)
     out = np.concatenate([rgb, sigma], -1).astype(F32)
     if keep:
-        return out, dict(acts=acts, h8=h, dir_in=dir_in, dir_h=dir_h, rgb=rgb)
+        return out, dict(acts=acts, h8=h, dir_in=dir_in, dir_h=dir_h, rgb=rgb, pres=pres, dir_pre=dir_pre)
     return out
 
 
-def nerf_backward(p: dict, cache: dict, grad_out: np.ndarray, sigma_only: bool = False) -> dict:
+def nerf_backward(p: dict, cache: dict, grad_out: np.ndarray, sigma_only: bool = False, masks: dict | None = None) -> dict:
     """Manual backward of nerf_forward w.r.t. every parameter (autograd of
-    nerf.py:83-124).  grad_out: (B,4) [d rgb, d sigma] or (B,1)."""
+    nerf.py:83-124).  grad_out: (B,4) [d rgb, d sigma] or (B,1).
+    masks (tests only): {'h': [8 x (B,256) bool], 'dir': (B,128) bool} -- the ReLU derivative masks (output > 0) to use
+    INSTEAD of the oracle's own: a pre-activation within rounding of 0 lands on either side of the kink under a different
+    fp32 summation order, and the parity tests exempt exactly those units by evaluating both sides with the same masks."""
     g = {}
+    mask_h = [None] * 8 if masks is None else list(masks["h"])
+    mask_dir = None if masks is None else masks.get("dir")
     B = grad_out.shape[0]
     h8 = cache["h8"]
     if sigma_only:
@@ -137,7 +146,7 @@ def nerf_backward(p: dict, cache: dict, grad_out: np.ndarray, sigma_only: bool =
         g["rgb.0.weight"] = d_pre.T @ cache["dir_h"]
         g["rgb.0.bias"] = d_pre.sum(0)
         d_dir_h = d_pre @ p["rgb.0.weight"]
-        d_dir_h = d_dir_h * (cache["dir_h"] > 0)
+        d_dir_h = d_dir_h * ((cache["dir_h"] > 0) if mask_dir is None else mask_dir)
         g["dir_encoding.0.weight"] = d_dir_h.T @ cache["dir_in"]
         g["dir_encoding.0.bias"] = d_dir_h.sum(0)
         d_final = (d_dir_h @ p["dir_encoding.0.weight"])[:, :256]
@@ -150,7 +159,7 @@ def nerf_backward(p: dict, cache: dict, grad_out: np.ndarray, sigma_only: bool =
     h_out = h8
     for i in reversed(range(8)):
         name = f"xyz_encoding_{i+1}.0"
-        d_pre = (d_h * (h_out > 0)).astype(F32)
+        d_pre = (d_h * ((h_out > 0) if mask_h[i] is None else mask_h[i])).astype(F32)
         x_in = cache["acts"][i]
         g[name + ".weight"] = d_pre.T @ x_in
         g[name + ".bias"] = d_pre.sum(0)

@@ -5,6 +5,7 @@ reference's files cannot travel to the GPU box, so this module restates the same
     models/rendering.py:105-262  render_rays / inference (sampling, chunked MLP calls, compositing, sample_pdf, sort)
     models/rendering.py:22-67    sample_pdf
     models/nerf.py:21-38, :83-124 Embedding, NeRF.forward
+    models/nerf.py:134-151, :201-216 the FiLM-SIREN field (round 3: the headline field of configs[1])
     losses.py:10-20, utils/__init__.py:20  MSE(coarse)+MSE(fine), torch.optim.Adam(lr 5e-4, eps 1e-8)
 -- with torch CPU ops (autograd for the backward), functional style over a dict of parameter tensors.  It exists for ONE
 purpose: bench.py's `cpu_baseline` leg (and the CPU test that pins it).  The numpy oracle (nerf_oracle.py) remains the
@@ -54,6 +55,38 @@ def nerf_mlp(P: dict, x: torch.Tensor, sigma_only: bool = False) -> torch.Tensor
     return torch.cat([rgb, sigma], -1)
 
 
+def siren_mlp(P: dict, x: torch.Tensor, sigma_only: bool = False) -> torch.Tensor:
+    """The FiLM-SIREN field of configs[1] as the reference's render_rays would evaluate it: SemanticNeRF.
+    forward_with_frequencies_phase_shifts (nerf.py:201-216; FiLMLayer :142-151, UniformBoxWarp(51) :134-140) behind the
+    field interface of rendering.py:105-159 -- forward(x, sigma_only) on the EMBEDDED rows, whose first three xyz / direction
+    channels are the raw xyz / direction (Embedding keeps its input, nerf.py:35).  The same adapter tools/make_psnr_golden.py
+    --siren trained the reference through (RefSirenField) and the product ships as nerf_siren_amd.SirenField.
+    P: the 22 state_dict tensors plus 'frequencies' / 'phase_shifts' (1, 2304), one conditioning row for all points."""
+    xyz = x[None, :, :3]
+    dirs = torch.zeros_like(xyz) if sigma_only else x[None, :, 63:66]
+    freq = P["frequencies"] * 15 + 30                        # :202
+    phase = P["phase_shifts"]
+
+    def film(name, h, lo, hi):                                # FiLMLayer.forward, :147-151
+        h = Fn.linear(h, P[name + ".layer.weight"], P[name + ".layer.bias"])
+        f = freq[..., lo:hi].unsqueeze(1).expand_as(h)
+        p = phase[..., lo:hi].unsqueeze(1).expand_as(h)
+        return torch.sin(f * h + p)
+    h = xyz * (2 / 51)                                        # gridwarper, :204
+    for i in range(8):
+        h = film(f"network.{i}", h, 256 * i, 256 * (i + 1))
+    sigma = Fn.linear(h, P["final_layer.weight"], P["final_layer.bias"])
+    if sigma_only:
+        return sigma[0]
+    c = film("color_layer_sine", torch.cat([dirs, h], -1), 2048, 2304)
+    rgb = torch.sigmoid(Fn.linear(c, P["color_layer_linear.0.weight"], P["color_layer_linear.0.bias"]))
+    return torch.cat([rgb, sigma], -1)[0]
+
+
+def field_mlp(P: dict, x: torch.Tensor, sigma_only: bool = False) -> torch.Tensor:
+    return siren_mlp(P, x, sigma_only) if "frequencies" in P else nerf_mlp(P, x, sigma_only)
+
+
 def sample_pdf(bins, weights, n_importance, det, u=None, eps=1e-5):
     """rendering.py:22-67."""
     n, nw = weights.shape
@@ -86,7 +119,7 @@ def _field_pass(P, rays_o, rays_d, dir_emb, z, noise_std, white_back, weights_on
         e = embed(xyz[i:i + chunk], 10)
         if not weights_only:
             e = torch.cat([e, dir_rep[i:i + chunk]], 1)
-        outs.append(nerf_mlp(P, e, sigma_only=weights_only))
+        outs.append(field_mlp(P, e, sigma_only=weights_only))
     out = torch.cat(outs, 0)
     if weights_only:
         sigmas = out.view(n, s)
@@ -237,8 +270,10 @@ def timed_sample(mode: str, params_np, make_rays, make_target, budget_s: float =
     info = host_info()
     info.update(pick_threads(info))
     torch.set_num_threads(info["threads"])
-    params = [{k: torch.from_numpy(v.copy()).requires_grad_(mode == "train") for k, v in p.items()} for p in params_np]
-    opt = torch.optim.Adam([t for p in params for t in p.values()], lr=5e-4, eps=1e-8) if mode == "train" else None
+    # the conditioning rows of a FiLM-SIREN field are inputs, not parameters (SirenField keeps them fixed)
+    params = [{k: torch.from_numpy(v.copy()).requires_grad_(mode == "train" and k not in ("frequencies", "phase_shifts"))
+               for k, v in p.items()} for p in params_np]
+    opt = torch.optim.Adam([t for p in params for t in p.values() if t.requires_grad], lr=5e-4, eps=1e-8) if mode == "train" else None
 
     def step(i):
         rays = torch.from_numpy(make_rays(i))

@@ -141,6 +141,27 @@ def test_hazard_scanner_recognises_the_pattern():
     far = bad.replace("s_waitcnt lgkmcnt(3)", "s_waitcnt lgkmcnt(3)\n\tv_add_f32_e32 v1, v2, v3")
     assert len(hs.scan_disassembly(bad)[3]) == 1 and hs.scan_disassembly(bad)[3][0][1] == 1
     assert hs.scan_disassembly(ok)[3] == [] and hs.scan_disassembly(far)[3] == []
+    # advisor (round 2): a conditional branch that is NOT taken falls straight through -- the write in front of it still
+    # counts; an unconditional branch ends the straight line; a write in front of a (back-)branch reaches the MFMA at its
+    # target label
+    fall = bad.replace("s_waitcnt lgkmcnt(3)", "s_cbranch_scc1 L9")
+    assert len(hs.scan_disassembly(fall)[3]) == 1
+    uncond = bad.replace("s_waitcnt lgkmcnt(3)", "s_branch L9")
+    assert hs.scan_disassembly(uncond)[3] == []
+    loop = """
+0000000000001000 <k>:
+\tv_mov_b32_e32 v1, 0
+\ts_nop 4
+0000000000001010 <L0>:
+\tv_mfma_f32_32x32x16_bf16 a[240:255], v[30:33], v[136:139], a[240:255]
+\ts_nop 7
+\tv_cvt_pk_bf16_f32 v137, v28, v38
+\ts_cbranch_scc1 L0
+\ts_endpgm
+"""
+    h = hs.scan_disassembly(loop)[3]
+    assert len(h) == 1 and h[0][1] == 1, h           # write, branch (one wait state), MFMA at the label
+    assert hs.scan_disassembly(loop.replace("s_cbranch_scc1 L0", "s_nop 0\n\ts_cbranch_scc1 L0"))[3] == []
 
 
 def test_no_valu_write_to_mfma_read_hazard_in_the_built_kernels(libpath):

@@ -432,6 +432,7 @@ def test_nerf_backward_kernels_vs_oracle(ops, dev, models, n_rays, P, fwd):
         ref = g_ref[name]
         assert tuple(g.shape) == ref.shape, name
         err = np.linalg.norm(N(g).astype(np.float64) - ref) / (np.linalg.norm(ref) + 1e-12)
+        print(f"MEASURE backward_kernels {fwd} {n_rays}x{P} {name} {err:.3e}")
         assert err < 5e-3, (name, err)          # ReLU-boundary flips under a different fp32 order, see oracle tests
 
 
@@ -476,6 +477,7 @@ def test_render_rays_training_gradients(golden, dev, models, case, math):
             den = np.linalg.norm(ref.astype(np.float64)) + 1e-12
             worst = max(worst, float(np.linalg.norm(mine.reshape(-1).astype(np.float64) - ref.reshape(-1)) / den))
         # coarse: independent of sample_pdf; fine: inherits its ill-conditioning (see test_oracle_golden.py)
+        print(f"MEASURE training_gradients {case} {math} model{mi} worst {worst:.3e}")
         assert worst < (5e-3 if mi == 0 else 2e-2), (mi, worst)
 
 
@@ -796,6 +798,7 @@ def test_eg3d_importance_and_unify(golden, dev):
     zo, _ = EO.sample_importance(g["depths"], g["weights"], 64, g["u"])
     assert np.array_equal(zf, zo)                                     # same specified arithmetic -> same bits
     err = np.abs(zf - g["z_fine"])
+    print(f"MEASURE eg3d_importance frac<1e-5 {(err < 1e-5).mean():.5f} max {err.max():.3e}")
     assert (err < 1e-5).mean() > 0.995 and err.max() < 0.2
     # unify: sorted depths + gathered payload
     n, m, s = 1, 37, 64
@@ -857,11 +860,13 @@ def test_eg3d_backward(golden, dev, osg, tag):
     ref_sub = g["gplanes_sub"]
     mine_sub = gp.reshape(-1)[::7]
     rel = np.linalg.norm(mine_sub.astype(np.float64) - ref_sub) / (np.linalg.norm(ref_sub.astype(np.float64)) + 1e-12)
+    print(f"MEASURE eg3d_backward {tag} planes {rel:.3e}")
     assert rel < 2e-2, rel              # fine samples inherit sample_pdf's conditioning (see the NeRF gradient tests)
     assert abs(np.linalg.norm(gp.astype(np.float64)) - float(g["gplanes_norm"])) < 2e-2 * float(g["gplanes_norm"])
     for k, p in osg.named_parameters():
         ref = g["gdec_" + k]
         err = np.linalg.norm(N(p.grad).astype(np.float64) - ref) / (np.linalg.norm(ref.astype(np.float64)) + 1e-12)
+        print(f"MEASURE eg3d_backward {tag} {k} {err:.3e}")
         assert err < 2e-2, (k, err)
 
 

@@ -402,6 +402,32 @@ def test_torch_cpu_ref_vs_reference(golden, case):
     assert max(w) < 1e-4, w
 
 
+def test_torch_cpu_ref_siren_field_vs_reference(golden):
+    """The FiLM-SIREN leg of oracle/torch_cpu_ref.py (bench.py's `cpu_baseline` on the headline workload): each of G8's three
+    conditioning rows through siren_mlp's field interface reproduces the imported SemanticNeRF's outputs (fixture g8) and,
+    under torch autograd, its parameter gradients (fixture g8b) to rounding."""
+    import torch
+    from oracle import torch_cpu_ref as TR
+    g, gg = golden("g8_siren"), golden("g8b_siren_grad")
+    base = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in synth.siren_params(3).items()}
+    loss = 0
+    for r in range(3):
+        P = dict(base, frequencies=torch.from_numpy(g["freq"][r:r + 1]), phase_shifts=torch.from_numpy(g["phase"][r:r + 1]))
+        x = torch.zeros(41, 90)
+        x[:, :3] = torch.from_numpy(g["inp"][r])
+        x[:, 63:66] = torch.from_numpy(g["dirs"][r])
+        out = TR.field_mlp(P, x)
+        np.testing.assert_allclose(out.detach().numpy(), g["out"][r], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(TR.field_mlp(P, x[:, :63], sigma_only=True).detach().numpy(), g["out"][r][:, 3:], rtol=0,
+                                   atol=2e-6)
+        loss = loss + (out * torch.from_numpy(gg["G"][r])).sum()
+    loss.backward()
+    for k, v in base.items():
+        ref = gg["grad_" + k]
+        rel = np.linalg.norm((v.grad.numpy() - ref).astype(np.float64)) / np.linalg.norm(ref.astype(np.float64))
+        assert rel < 1e-5, (k, rel)
+
+
 def test_torch_cpu_ref_host_info_and_sample():
     from oracle import torch_cpu_ref as TR
     info = TR.host_info()
@@ -410,6 +436,12 @@ def test_torch_cpu_ref_host_info_and_sample():
     out = TR.timed_sample("infer", ps, lambda i: synth.blender_rays(64, seed=i), None, budget_s=0.2, n_rays=64, max_steps=2)
     assert out["steps"] >= 1 and out["ray_samples_per_s"] > 0 and "parallel_info" in out
     assert 1 <= out["threads"] <= out["nproc"] and str(out["threads"]) in out["gemm_gflops"]
+    # the headline workload: FiLM-SIREN fields (conditioning rows are inputs, not optimised)
+    sp = [dict(synth.siren_params(s), frequencies=synth.hash_normal((1, 2304), 10 + s), phase_shifts=synth.hash_normal((1, 2304), 20 + s))
+          for s in (1, 2)]
+    out = TR.timed_sample("train", sp, lambda i: synth.blender_rays(16, seed=i), lambda i: synth.hash_uniform((16, 3), i),
+                          budget_s=0.2, n_rays=16, max_steps=1)
+    assert out["steps"] == 1 and out["ray_samples_per_s"] > 0
 
 
 # --------------------------------------------------------------------------- f1 / f3 pinned by the reference's own code

@@ -35,21 +35,43 @@ def _regs(tok: str):
     return []
 
 
-def scan_disassembly(text: str):
-    """-> (kernels, instructions, mfmas, hits); a hit = (kernel, wait_states, writer, mfma)."""
-    kern, hits, n_ins, n_mfma, kernels = None, [], 0, 0, 0
-    last_def, t = {}, 0
+def _parse(text: str):
+    """-> list of kernels, each a list of ('label', name) / ('ins', op, operands, text) in address order
+    (llvm-objdump --symbolize-operands: branch targets are printed as L<n> and defined by '<L<n>>:' lines)."""
+    kernels, cur = [], None
     for line in text.split("\n"):
         m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
         if m:
-            kern, last_def, t = m.group(1), {}, 0
-            kernels += 1
+            if re.fullmatch(r"L\d+", m.group(1)):
+                if cur is not None:
+                    cur[1].append(("label", m.group(1)))
+            else:
+                cur = (m.group(1), [])
+                kernels.append(cur)
             continue
         ins = line.split("//")[0].strip()
-        if not ins or kern is None:
+        if not ins or cur is None:
             continue
         op, _, rest = ins.partition(" ")
-        ops = [o.strip() for o in rest.split(",")] if rest else []
+        cur[1].append(("ins", op, [o.strip() for o in rest.split(",")] if rest else [], ins))
+    return kernels
+
+
+def _walk(items, incoming, record):
+    """One linear pass over a kernel.  last_def: VGPR -> (slot after which it is readable - NEED bookkeeping, writer).
+    A CONDITIONAL branch falls through, so the state survives it; only an unconditional branch / s_setpc ends the straight
+    line.  At a label the tails of ALL predecessors meet: every branch to the label hands over the registers it saw written
+    within the last NEED slots (`incoming`, filled when record=True), merged conservatively (latest write wins).
+    -> (instructions, mfmas, hits)"""
+    last_def, t, n_ins, n_mfma, hits = {}, 0, 0, 0, []
+    for it in items:
+        if it[0] == "label":
+            for elapsed, r, writer in incoming.get(it[1], ()):
+                cand = t - elapsed
+                if r not in last_def or cand > last_def[r][0]:
+                    last_def[r] = (cand, writer)
+            continue
+        _, op, ops, ins = it
         if op == "s_nop":
             t += int(ops[0], 0) + 1
             continue
@@ -60,16 +82,37 @@ def scan_disassembly(text: str):
                 for r in _regs(o.split(" ")[0]):
                     d = last_def.get(r)
                     if d is not None and t - d[0] < NEED:
-                        hits.append((kern, t - d[0], d[1], ins))
+                        hits.append((t - d[0], d[1], ins))
             t += 1
             continue
         if op.startswith("v_") and ops:
             for r in _regs(ops[0].split(" ")[0]):
                 last_def[r] = (t + 1, ins)          # the next instruction issues 0 wait states after this one
-        if op.startswith("s_cbranch") or op == "s_branch" or op.startswith("s_setpc"):
-            last_def = {}                             # straight-line check only
         t += 1
-    return kernels, n_ins, n_mfma, hits
+        if op.startswith("s_cbranch") or op == "s_branch":
+            target = ops[0] if ops else ""
+            if record and re.fullmatch(r"L\d+", target):
+                tail = [(t - d[0], r, d[1]) for r, d in last_def.items() if t - d[0] < NEED]
+                if tail:
+                    incoming.setdefault(target, []).extend(tail)
+        if op == "s_branch" or op.startswith("s_setpc"):
+            last_def = {}                             # nothing falls through an unconditional branch
+    return n_ins, n_mfma, hits
+
+
+def scan_disassembly(text: str):
+    """-> (kernels, instructions, mfmas, hits); a hit = (kernel, wait_states, writer, mfma)."""
+    n_ins = n_mfma = 0
+    hits = []
+    kernels = _parse(text)
+    for name, items in kernels:
+        incoming = {}
+        _walk(items, incoming, record=True)          # pass 1: what every branch carries to its target
+        a, b, h = _walk(items, incoming, record=False)
+        n_ins += a
+        n_mfma += b
+        hits += [(name,) + x for x in h]
+    return len(kernels), n_ins, n_mfma, hits
 
 
 def code_objects(path: str, tmp: str):
@@ -79,6 +122,9 @@ def code_objects(path: str, tmp: str):
     if head[:4] == b"\x7fELF" and head[18:20] == b"\xe0\x00":          # e_machine = EM_AMDGPU
         return [path]
     fat = os.path.join(tmp, os.path.basename(path) + ".fatbin")
+    sections = subprocess.run([f"{LLVM}/llvm-readelf", "-S", path], check=True, capture_output=True, text=True).stdout
+    if ".hip_fatbin" not in sections:                # a host-only translation unit (csrc/render.hip): no device code
+        return []
     subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", path], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     out = os.path.join(tmp, os.path.basename(path) + ".co")
@@ -92,7 +138,7 @@ def scan_file(path: str):
     with tempfile.TemporaryDirectory() as tmp:
         res = []
         for co in code_objects(path, tmp):
-            dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True,
+            dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", "--symbolize-operands", co], check=True, capture_output=True,
                                  text=True).stdout
             res.append(scan_disassembly(dis))
         return res
