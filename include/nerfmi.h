@@ -332,6 +332,11 @@ int nerfmi_eg3d_run_model_rays(const float *planes_hwc, int n, int h, int w, con
 int nerfmi_eg3d_sample_stratified(const float *ray_start_t, const float *ray_end_t, float ray_start, float ray_end,
                                   const float *rand, int64_t n_rays, int n_samples, int disparity, float *depths_out,
                                   nerfmi_stream_t stream);
+/* The same with the draw made IN the kernel from the Philox stream (seed, offset), segment 0 -- element e of the draw is what
+ * nerfmi_render_draws(seed, offset, ...) writes at perturb_rand[e]. */
+int nerfmi_eg3d_sample_stratified_philox(const float *ray_start_t, const float *ray_end_t, float ray_start, float ray_end,
+                                         uint64_t seed, uint64_t offset, int64_t n_rays, int n_samples, int disparity,
+                                         float *depths_out, nerfmi_stream_t stream);
 /* torch.min / torch.max over all depths of the call (ray_marcher.py:50) -> minmax_out[2] on the device. */
 int nerfmi_eg3d_minmax(const float *x, int64_t n, float *minmax_out, nerfmi_stream_t stream);
 /* MipRayMarcher2.run_forward (ray_marcher.py:25-57): colors (R,S,3), densities (R,S), depths (R,S) ->
@@ -342,6 +347,10 @@ int nerfmi_eg3d_march(const float *colors, const float *densities, const float *
 /* sample_importance (renderer.py:197-256): depths (R,S), weights (R,S-1), u (R,F) = the torch.rand draw -> z_out (R,F). */
 int nerfmi_eg3d_sample_importance(const float *depths, const float *weights, const float *u, int64_t n_rays,
                                   int n_samples, int n_importance, float *z_out, nerfmi_stream_t stream);
+/* ... with u drawn in the kernel: segment 2 of the Philox stream (seed, offset) (= nerfmi_render_draws' `u`). */
+int nerfmi_eg3d_sample_importance_philox(const float *depths, const float *weights, uint64_t seed, uint64_t offset,
+                                         int64_t n_rays, int n_samples, int n_importance, float *z_out,
+                                         nerfmi_stream_t stream);
 /* unify_samples (renderer.py:160-170): sort by depth and gather colours (.,3) and densities.
  * idx_out (R, n1+n2) int32, optional: source position of every sorted sample (for the backward). */
 int nerfmi_eg3d_unify(const float *d1, const float *c1, const float *s1, const float *d2, const float *c2,

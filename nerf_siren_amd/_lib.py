@@ -64,9 +64,11 @@ SIGNATURES = {
     "nerfmi_eg3d_run_model": (_i, [_f, _i, _i, _i, _f, _f, _i64, _fl, _f, _f, _f]),
     "nerfmi_eg3d_run_model_rays": (_i, [_f, _i, _i, _i, _f, _f, _f, _f, _i64, _i, _fl, _f, _f, _f]),
     "nerfmi_eg3d_sample_stratified": (_i, [_f, _f, _fl, _fl, _f, _i64, _i, _i, _f, _f]),
+    "nerfmi_eg3d_sample_stratified_philox": (_i, [_f, _f, _fl, _fl, C.c_uint64, C.c_uint64, _i64, _i, _i, _f, _f]),
     "nerfmi_eg3d_minmax": (_i, [_f, _i64, _f, _f]),
     "nerfmi_eg3d_march": (_i, [_f, _f, _f, _f, _i64, _i, _i, _f, _f, _f, _f, _f]),
     "nerfmi_eg3d_sample_importance": (_i, [_f, _f, _f, _i64, _i, _i, _f, _f]),
+    "nerfmi_eg3d_sample_importance_philox": (_i, [_f, _f, C.c_uint64, C.c_uint64, _i64, _i, _i, _f, _f]),
     "nerfmi_eg3d_unify": (_i, [_f, _f, _f, _f, _f, _f, _i64, _i, _i, _f, _f, _f, _f, _f]),
     "nerfmi_eg3d_march_backward": (_i, [_f, _f, _f, _f, _f, _f, _f, _i64, _i, _i, _i, _f, _f, _f]),
     "nerfmi_eg3d_unify_backward": (_i, [_f, _f, _f, _i64, _i, _i, _f, _f, _f, _f, _f]),
@@ -101,6 +103,27 @@ class NerfmiError(RuntimeError):
     pass
 
 
+def load_shared(path=None):
+    """ctypes.CDLL of libnerfmi.so bound to the SAME HIP runtime PyTorch uses.
+
+    PyTorch-ROCm ships its own libamdhip64.so / libhsa-runtime64.so and loads them only when torch.cuda initialises.  If
+    libnerfmi.so is dlopen-ed BEFORE that, the loader resolves its `libamdhip64.so.7` dependency to /opt/rocm's copy, the
+    process ends up with two HIP runtimes, and the second one to open the device finds none: the library's first launch
+    fails with "no ROCm-capable device is detected" (seen in round 3: build() loaded the library, then smoke() ran in the
+    same process).  Loading torch's copy first (by path, RTLD_GLOBAL) makes the later dependency lookup hit the already
+    loaded SONAME whatever the order.  Without a bundled runtime (or without torch) the system copy is the only one."""
+    try:
+        import torch
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            p = os.path.join(tl, name)
+            if os.path.exists(p):
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError):
+        pass
+    return C.CDLL(path or LIB_PATH)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -109,7 +132,7 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is not built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
                 "nerf_siren_amd has no CPU/PyTorch fallback.")
-        l = C.CDLL(LIB_PATH)
+        l = load_shared()
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype = res

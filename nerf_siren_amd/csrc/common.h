@@ -18,6 +18,13 @@ void set_error(const char *fmt, ...);
         }                                         \
     } while (0)
 
+// First statement of every entry point that launches: forget an error some OTHER user of the (process-wide, shared) HIP
+// runtime left in this thread's last-error slot -- PyTorch probes devices and peers through the same runtime, and
+// check_launch() below would otherwise report its stale hipErrorNoDevice as this call's failure (seen in round 3: the first
+// nerfmi call of a fresh process raised "no ROCm-capable device is detected" right after torch had put tensors on that
+// device).
+#define NERFMI_ENTER() (void)hipGetLastError()
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -13,7 +13,7 @@
 // held in SGPRs via uniform loads) is fused behind the gather, one sample per
 // lane, and the features never exist in memory.  Per-ray kernels (marcher,
 // importance resampling, unify) use one wavefront per ray like rays.hip.
-#include "common.h"
+#include "philox.h"
 
 namespace nerfmi {
 
@@ -163,26 +163,29 @@ __device__ __forceinline__ float linspace_at(float start, float end, int i, int 
 
 // per_ray: start/end are (R) tensors (the 'auto' branch, math_utils.linspace); else scalars start_s/end_s
 __global__ void eg3d_stratified_kernel(const float *__restrict__ start_t, const float *__restrict__ end_t, float start_s,
-                                       float end_s, float delta_s, const float *__restrict__ rand, int64_t R, int S,
-                                       int disparity, float *__restrict__ out) {
+                                       float end_s, float delta_s, const float *__restrict__ rand, DrawKey key, int64_t R,
+                                       int S, int disparity, float *__restrict__ out) {
     const int64_t total = R * S;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(idx % S);
         const int64_t r = idx / S;
+        // torch.rand_like of renderer.py:172-195: the injected tensor, or element idx of segment 0 of the call's Philox stream
+        // (philox.h) drawn here -- no aten distribution launch, no tensor of draws
+        const float rnd = rand ? rand[idx] : draw_one(key, idx);
         float d;
         if (start_t) {
             const float a = start_t[r], b = end_t[r], span = __fsub_rn(b, a);
             const float step = __fdiv_rn((float)i, (float)(S - 1));
             d = __fadd_rn(a, __fmul_rn(step, span));
-            d = __fadd_rn(d, __fmul_rn(rand[idx], __fdiv_rn(span, (float)(S - 1))));
+            d = __fadd_rn(d, __fmul_rn(rnd, __fdiv_rn(span, (float)(S - 1))));
         } else if (disparity) {
             float t = linspace01(i, S);
-            t = __fadd_rn(t, __fmul_rn(rand[idx], delta_s));
+            t = __fadd_rn(t, __fmul_rn(rnd, delta_s));
             const float a = __fmul_rn(start_s, __fsub_rn(1.f, t)), b = __fmul_rn(end_s, t);   // start_s/end_s = 1/ray_start, 1/ray_end
             d = __fdiv_rn(1.f, __fadd_rn(a, b));
         } else {
-            d = __fadd_rn(linspace_at(start_s, end_s, i, S), __fmul_rn(rand[idx], delta_s));
+            d = __fadd_rn(linspace_at(start_s, end_s, i, S), __fmul_rn(rnd, delta_s));
         }
         out[idx] = d;
     }
@@ -302,7 +305,7 @@ mip_march_kernel(const float *__restrict__ colors, const float *__restrict__ den
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 eg3d_importance_kernel(const float *__restrict__ depths, const float *__restrict__ weights, const float *__restrict__ u,
-                       int64_t R, int S, int F, float *__restrict__ out) {
+                       DrawKey key, int64_t R, int S, int F, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
     const int NI = S - 1;            // weights per ray
@@ -343,7 +346,7 @@ eg3d_importance_kernel(const float *__restrict__ depths, const float *__restrict
         if (lane == 0) cdf[0] = 0.f;
         __syncthreads();
         for (int f = lane; f < F; f += WAVE) {
-            const float uu = u[r * F + f];
+            const float uu = u ? u[r * F + f] : draw_one(key, r * F + f);    // renderer.py:230 torch.rand: injected, or drawn here
             int lo = 0, hi = nw + 1;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= uu) lo = mid + 1; else hi = mid; }
             const int below = max(lo - 1, 0), above = min(lo, nw);
@@ -470,6 +473,7 @@ extern "C" {
 
 int nerfmi_eg3d_pack_planes(const float *planes_nchw, int n_planes, int channels, int h, int w, float *planes_hwc,
                             nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_planes >= 1 && channels == EC && h >= 1 && w >= 1, "eg3d_pack_planes: need %d channels, got %d", EC, channels);
     NERFMI_REQUIRE(planes_nchw && planes_hwc, "eg3d_pack_planes: null pointer");
     const int64_t total = (int64_t)n_planes * channels * h * w;
@@ -482,6 +486,7 @@ size_t nerfmi_eg3d_decoder_floats(void) { return (size_t)DEC_FLOATS; }
 
 int nerfmi_eg3d_pack_decoder(const float *w0, const float *b0, const float *w1, const float *b1, float lr_multiplier,
                              float *packed, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(w0 && b0 && w1 && b1 && packed, "eg3d_pack_decoder: null pointer");
     hipLaunchKernelGGL(pack_decoder_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w0, b0, w1, b1, lr_multiplier, packed);
     return check_launch("eg3d_pack_decoder");
@@ -489,6 +494,7 @@ int nerfmi_eg3d_pack_decoder(const float *w0, const float *b0, const float *w1, 
 
 int nerfmi_eg3d_sample_planes(const float *planes_hwc, int n, int h, int w, const float *coords, int64_t n_points,
                               float box_warp, float *feats_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 1 && h >= 1 && w >= 1 && n_points >= 0 && box_warp != 0.f, "eg3d_sample_planes: bad sizes");
     if (n_points == 0) return NERFMI_OK;
     NERFMI_REQUIRE(planes_hwc && coords && feats_out, "eg3d_sample_planes: null pointer");
@@ -502,6 +508,7 @@ int nerfmi_eg3d_sample_planes(const float *planes_hwc, int n, int h, int w, cons
 int nerfmi_eg3d_run_model(const float *planes_hwc, int n, int h, int w, const float *decoder_packed,
                           const float *coords, int64_t n_points, float box_warp, float *rgb_out, float *sigma_out,
                           nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 1 && h >= 1 && w >= 1 && n_points >= 0 && box_warp != 0.f, "eg3d_run_model: bad sizes");
     if (n_points == 0) return NERFMI_OK;
     NERFMI_REQUIRE(planes_hwc && decoder_packed && coords && rgb_out && sigma_out, "eg3d_run_model: null pointer");
@@ -516,6 +523,7 @@ int nerfmi_eg3d_run_model_rays(const float *planes_hwc, int n, int h, int w, con
                                const float *ray_origins, const float *ray_directions, const float *depths,
                                int64_t n_rays_per_batch, int n_samples, float box_warp, float *rgb_out,
                                float *sigma_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 1 && h >= 1 && w >= 1 && n_rays_per_batch >= 0 && n_samples >= 1 && box_warp != 0.f,
                    "eg3d_run_model_rays: bad sizes");
     const int64_t P = n_rays_per_batch * n_samples;
@@ -529,12 +537,13 @@ int nerfmi_eg3d_run_model_rays(const float *planes_hwc, int n, int h, int w, con
     return check_launch("eg3d_run_model_rays");
 }
 
-int nerfmi_eg3d_sample_stratified(const float *ray_start_t, const float *ray_end_t, float ray_start, float ray_end,
-                                  const float *rand, int64_t n_rays, int n_samples, int disparity, float *depths_out,
-                                  nerfmi_stream_t stream) {
+static int eg3d_sample_stratified_impl(const float *ray_start_t, const float *ray_end_t, float ray_start, float ray_end,
+                                       const float *rand, DrawKey key, int64_t n_rays, int n_samples, int disparity,
+                                       float *depths_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 2, "eg3d_sample_stratified: bad sizes");
     if (n_rays == 0) return NERFMI_OK;
-    NERFMI_REQUIRE(rand && depths_out, "eg3d_sample_stratified: null pointer");
+    NERFMI_REQUIRE((rand || key.on) && depths_out, "eg3d_sample_stratified: null pointer");
     NERFMI_REQUIRE((ray_start_t == nullptr) == (ray_end_t == nullptr), "eg3d_sample_stratified: start/end tensors come in pairs");
     float s = ray_start, e = ray_end, delta;
     if (disparity) {
@@ -545,11 +554,27 @@ int nerfmi_eg3d_sample_stratified(const float *ray_start_t, const float *ray_end
         delta = (float)(((double)ray_end - (double)ray_start) / (n_samples - 1));
     }
     hipLaunchKernelGGL(eg3d_stratified_kernel, dim3(grid_for(n_rays * n_samples, 256)), dim3(256), 0, (hipStream_t)stream,
-                       ray_start_t, ray_end_t, s, e, delta, rand, n_rays, n_samples, disparity, depths_out);
+                       ray_start_t, ray_end_t, s, e, delta, rand, key, n_rays, n_samples, disparity, depths_out);
     return check_launch("eg3d_sample_stratified");
 }
 
+int nerfmi_eg3d_sample_stratified(const float *ray_start_t, const float *ray_end_t, float ray_start, float ray_end,
+                                  const float *rand, int64_t n_rays, int n_samples, int disparity, float *depths_out,
+                                  nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(rand || n_rays == 0, "eg3d_sample_stratified: null pointer");
+    return eg3d_sample_stratified_impl(ray_start_t, ray_end_t, ray_start, ray_end, rand, DrawKey{0, 0, 0, 0}, n_rays, n_samples,
+                                       disparity, depths_out, stream);
+}
+
+int nerfmi_eg3d_sample_stratified_philox(const float *ray_start_t, const float *ray_end_t, float ray_start, float ray_end,
+                                         uint64_t seed, uint64_t offset, int64_t n_rays, int n_samples, int disparity,
+                                         float *depths_out, nerfmi_stream_t stream) {
+    return eg3d_sample_stratified_impl(ray_start_t, ray_end_t, ray_start, ray_end, nullptr, DrawKey{seed, offset, 0, 1}, n_rays,
+                                       n_samples, disparity, depths_out, stream);
+}
+
 int nerfmi_eg3d_minmax(const float *x, int64_t n, float *minmax_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 1 && x && minmax_out, "eg3d_minmax: bad arguments");
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, minmax_out);
     const int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
@@ -561,6 +586,7 @@ int nerfmi_eg3d_minmax(const float *x, int64_t n, float *minmax_out, nerfmi_stre
 int nerfmi_eg3d_march(const float *colors, const float *densities, const float *depths, const float *minmax,
                       int64_t n_rays, int n_samples, int white_back, float *rgb_out, float *depth_out,
                       float *weights_out, float *weight_sum_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 2 && n_samples <= 1025, "eg3d_march: n_samples=%d out of [2,1025]", n_samples);
     if (n_rays == 0) return NERFMI_OK;
     NERFMI_REQUIRE(colors && densities && depths && minmax && rgb_out && depth_out, "eg3d_march: null pointer");
@@ -574,20 +600,35 @@ int nerfmi_eg3d_march(const float *colors, const float *densities, const float *
     return check_launch("eg3d_march");
 }
 
-int nerfmi_eg3d_sample_importance(const float *depths, const float *weights, const float *u, int64_t n_rays,
-                                  int n_samples, int n_importance, float *z_out, nerfmi_stream_t stream) {
+static int eg3d_sample_importance_impl(const float *depths, const float *weights, const float *u, DrawKey key, int64_t n_rays,
+                                       int n_samples, int n_importance, float *z_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 4 && n_samples <= 4096 && n_importance >= 1, "eg3d_sample_importance: bad sizes");
     if (n_rays == 0) return NERFMI_OK;
-    NERFMI_REQUIRE(depths && weights && u && z_out, "eg3d_sample_importance: null pointer");
+    NERFMI_REQUIRE(depths && weights && (u || key.on) && z_out, "eg3d_sample_importance: null pointer");
     const size_t lds = sizeof(float) * (3 * (size_t)n_samples + 8);
     hipLaunchKernelGGL(eg3d_importance_kernel, dim3((unsigned)(n_rays < 65536 ? n_rays : 65536)), dim3(64), lds,
-                       (hipStream_t)stream, depths, weights, u, n_rays, n_samples, n_importance, z_out);
+                       (hipStream_t)stream, depths, weights, u, key, n_rays, n_samples, n_importance, z_out);
     return check_launch("eg3d_sample_importance");
+}
+
+int nerfmi_eg3d_sample_importance(const float *depths, const float *weights, const float *u, int64_t n_rays,
+                                  int n_samples, int n_importance, float *z_out, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(u || n_rays == 0, "eg3d_sample_importance: null pointer");
+    return eg3d_sample_importance_impl(depths, weights, u, DrawKey{0, 0, 0, 0}, n_rays, n_samples, n_importance, z_out, stream);
+}
+
+int nerfmi_eg3d_sample_importance_philox(const float *depths, const float *weights, uint64_t seed, uint64_t offset,
+                                         int64_t n_rays, int n_samples, int n_importance, float *z_out,
+                                         nerfmi_stream_t stream) {
+    return eg3d_sample_importance_impl(depths, weights, nullptr, DrawKey{seed, offset, 2, 1}, n_rays, n_samples, n_importance,
+                                       z_out, stream);
 }
 
 int nerfmi_eg3d_unify(const float *d1, const float *c1, const float *s1, const float *d2, const float *c2,
                       const float *s2, int64_t n_rays, int n1, int n2, float *d_out, float *c_out, float *s_out,
                       int32_t *idx_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n1 >= 1 && n2 >= 0 && n1 + n2 <= 8192, "eg3d_unify: bad sizes");
     if (n_rays == 0) return NERFMI_OK;
     NERFMI_REQUIRE(d1 && c1 && s1 && (n2 == 0 || (d2 && c2 && s2)) && d_out && c_out && s_out, "eg3d_unify: null pointer");
@@ -600,6 +641,7 @@ int nerfmi_eg3d_unify(const float *d1, const float *c1, const float *s1, const f
 
 int nerfmi_eg3d_ray_sampler(const float *cam2world, const float *intrinsics, int n, int resolution, float *origins_out,
                             float *dirs_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 0 && resolution >= 1, "eg3d_ray_sampler: bad sizes");
     if (n == 0) return NERFMI_OK;
     NERFMI_REQUIRE(cam2world && intrinsics && origins_out && dirs_out, "eg3d_ray_sampler: null pointer");
@@ -610,6 +652,7 @@ int nerfmi_eg3d_ray_sampler(const float *cam2world, const float *intrinsics, int
 
 int nerfmi_eg3d_ray_limits_box(const float *rays_o, const float *rays_d, int64_t n, float box_side_length,
                                float *tmin_out, float *tmax_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 0, "eg3d_ray_limits_box: bad size");
     if (n == 0) return NERFMI_OK;
     NERFMI_REQUIRE(rays_o && rays_d && tmin_out && tmax_out, "eg3d_ray_limits_box: null pointer");

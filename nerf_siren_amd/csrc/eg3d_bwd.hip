@@ -415,6 +415,7 @@ int nerfmi_eg3d_march_backward(const float *colors, const float *densities, cons
                                const float *g_rgb, const float *g_depth, const float *g_weight_sum, int64_t n_rays,
                                int n_samples, int white_back, int accumulate, float *d_colors, float *d_densities,
                                nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 2 && n_samples <= 1025, "eg3d_march_backward: n_samples=%d out of [2,1025]", n_samples);
     if (n_rays == 0) return NERFMI_OK;
     NERFMI_REQUIRE(colors && densities && depths && minmax && d_colors && d_densities, "eg3d_march_backward: null pointer");
@@ -432,6 +433,7 @@ int nerfmi_eg3d_march_backward(const float *colors, const float *densities, cons
 
 int nerfmi_eg3d_unify_backward(const int32_t *idx, const float *g_colors, const float *g_densities, int64_t n_rays, int n1,
                                int n2, float *d_c1, float *d_s1, float *d_c2, float *d_s2, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n1 >= 1 && n2 >= 0, "eg3d_unify_backward: bad sizes");
     if (n_rays == 0) return NERFMI_OK;
     NERFMI_REQUIRE(idx && g_colors && g_densities && d_c1 && d_s1 && (n2 == 0 || (d_c2 && d_s2)), "eg3d_unify_backward: null pointer");
@@ -447,6 +449,7 @@ int nerfmi_eg3d_run_model_rays_backward(const float *planes_hwc, int n, int h, i
                                         const float *ray_origins, const float *ray_directions, const float *depths,
                                         int64_t n_rays_per_batch, int n_samples, float box_warp, const float *d_rgb,
                                         const float *d_sigma, float *gplanes_hwc, float *aux, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 1 && h >= 1 && w >= 1 && n_rays_per_batch >= 0 && n_samples >= 1 && box_warp != 0.f,
                    "eg3d_run_model_rays_backward: bad sizes");
     const int64_t P = n_rays_per_batch * n_samples;
@@ -467,6 +470,7 @@ int nerfmi_eg3d_run_model_rays_backward(const float *planes_hwc, int n, int h, i
 
 int nerfmi_eg3d_decoder_wgrad(const float *aux, int64_t n_points, float lr_multiplier, int accumulate, float *partial,
                               float *g_w0, float *g_b0, float *g_w1, float *g_b1, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_points >= 1 && aux && partial && g_w0 && g_b0 && g_w1 && g_b1, "eg3d_decoder_wgrad: bad arguments");
     const int64_t aux_ld = (n_points + 63) / 64 * 64;
     hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(WGRAD_CHUNKS), dim3(256), 0, (hipStream_t)stream, aux, aux_ld, n_points,
@@ -478,6 +482,7 @@ int nerfmi_eg3d_decoder_wgrad(const float *aux, int64_t n_points, float lr_multi
 
 int nerfmi_eg3d_unpack_planes(const float *planes_hwc, int n_planes, int channels, int h, int w, float *planes_nchw,
                               nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_planes >= 1 && channels >= 1 && h >= 1 && w >= 1 && planes_hwc && planes_nchw, "eg3d_unpack_planes: bad arguments");
     const int64_t total = (int64_t)n_planes * channels * h * w;
     hipLaunchKernelGGL(unpack_planes_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, planes_hwc,

@@ -291,6 +291,7 @@ int nerfmi_debug_timing(unsigned long long *host) {
 size_t nerfmi_nerf_packed_floats(void) { return (size_t)PACKED_FLOATS; }
 
 int nerfmi_nerf_pack(const float *const *params, float *packed, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(params && packed, "nerf_pack: null pointer");
     ParamPtrs P;
     for (int i = 0; i < N_PARAMS; ++i) {
@@ -306,6 +307,7 @@ size_t nerfmi_nerf_saved_floats(int64_t n_points) { return (size_t)SAVED_ROWS * 
 
 int nerfmi_nerf_forward_rays(const float *packed, const float *rays, const float *z, int n_rays, int n_per_ray,
                              int sigma_only, float *out, float *saved, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1, "nerf_forward_rays: bad sizes");
     const int64_t n_points = (int64_t)n_rays * n_per_ray;
     if (n_points == 0) return NERFMI_OK;
@@ -331,6 +333,7 @@ int nerfmi_nerf_forward_rays(const float *packed, const float *rays, const float
 
 int nerfmi_nerf_forward_embedded(const float *packed, const float *x, int64_t n, int sigma_only, float *out,
                                  nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 0, "nerf_forward_embedded: bad size");
     if (n == 0) return NERFMI_OK;
     NERFMI_REQUIRE(packed && x && out, "nerf_forward_embedded: null pointer");
@@ -349,6 +352,7 @@ int nerfmi_nerf_forward_embedded(const float *packed, const float *x, int64_t n,
 // NeRF.forward(x) on pre-embedded rows with the activations saved for nerfmi_nerf_backward_rays(n_rays = n, n_per_ray = 1)
 int nerfmi_nerf_forward_embedded_train(const float *packed, const float *x, int64_t n, float *out, float *saved,
                                        nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 0, "nerf_forward_embedded_train: bad size");
     if (n == 0) return NERFMI_OK;
     NERFMI_REQUIRE(packed && x && out && saved, "nerf_forward_embedded_train: null pointer");

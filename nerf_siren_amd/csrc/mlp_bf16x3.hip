@@ -244,6 +244,7 @@ int nerfmi_debug_timing_fast(unsigned long long *host) {
 size_t nerfmi_nerf_fast_bytes(void) { return (size_t)(FAST_FWD_UNITS + FAST_T_UNITS) * 3072 + FAST_TAIL_BYTES; }
 
 int nerfmi_nerf_pack_fast(const float *packed, void *fast, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(packed && fast, "nerf_pack_fast: null pointer");
     hipLaunchKernelGGL(pack_bf16x3_table_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, nerf_fast_table(), packed,
                        (__bf16 *)fast);
@@ -252,6 +253,7 @@ int nerfmi_nerf_pack_fast(const float *packed, void *fast, nerfmi_stream_t strea
 
 int nerfmi_nerf_forward_rays_fast(const float *packed, const void *fast, const float *rays, const float *z, int n_rays,
                                   int n_per_ray, int sigma_only, float *out, float *saved, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1, "nerf_forward_rays_fast: bad sizes");
     const int64_t n_points = (int64_t)n_rays * n_per_ray;
     if (n_points == 0) return NERFMI_OK;

@@ -534,6 +534,7 @@ extern "C" int nerfmi_debug_timing_dw(unsigned long long *host) {
 static int backward_impl(const char *who, const float *packed, const void *fast, int n_rays, int n_per_ray,
                          const float *saved, const float *grad_out, float *const *grad_params, float *workspace,
                          nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 1 && n_per_ray >= 1, "%s: bad sizes", who);
     NERFMI_REQUIRE(packed && saved && grad_out && grad_params && workspace, "%s: null pointer", who);
     const int64_t n_points = (int64_t)n_rays * n_per_ray;

@@ -143,6 +143,7 @@ using namespace nerfmi;
 extern "C" {
 
 int nerfmi_ray_directions(int H, int W, double focal, float *dirs_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(H >= 1 && W >= 1 && focal > 0, "ray_directions: H, W >= 1 and focal > 0 required");
     NERFMI_REQUIRE(dirs_out, "ray_directions: null pointer");
     const int64_t n = (int64_t)H * W;
@@ -153,6 +154,7 @@ int nerfmi_ray_directions(int H, int W, double focal, float *dirs_out, nerfmi_st
 
 int nerfmi_get_rays(const float *directions, const float *c2w, int64_t n, float *rays_o_out, float *rays_d_out,
                     nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 0, "get_rays: n must be >= 0");
     if (n == 0) return NERFMI_OK;
     NERFMI_REQUIRE(directions && c2w && rays_o_out && rays_d_out, "get_rays: null pointer");
@@ -163,6 +165,7 @@ int nerfmi_get_rays(const float *directions, const float *c2w, int64_t n, float 
 
 int nerfmi_ndc_rays(int H, int W, double focal, double near, const float *rays_o, const float *rays_d, int64_t n,
                     float *rays_o_out, float *rays_d_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(H >= 1 && W >= 1 && focal > 0 && n >= 0, "ndc_rays: bad sizes");
     if (n == 0) return NERFMI_OK;
     NERFMI_REQUIRE(rays_o && rays_d && rays_o_out && rays_d_out, "ndc_rays: null pointer");
@@ -173,6 +176,7 @@ int nerfmi_ndc_rays(int H, int W, double focal, double near, const float *rays_o
 
 int nerfmi_generate_rays(const float *c2w, int n_images, int H, int W, double focal, const int64_t *pixel_index,
                          int64_t n_rays, int ndc, double near, double far, float *rays_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_images >= 1 && H >= 1 && W >= 1 && focal > 0 && n_rays >= 0, "generate_rays: bad sizes");
     NERFMI_REQUIRE(pixel_index || n_rays == (int64_t)n_images * H * W,
                    "generate_rays: without pixel_index n_rays must be n_images*H*W");
@@ -188,6 +192,7 @@ int nerfmi_generate_rays(const float *c2w, int n_images, int H, int W, double fo
 
 int nerfmi_create_samples(int N, double origin_x, double origin_y, double origin_z, double voxel_size, float *samples_out,
                           nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(N >= 2 && N <= 1024, "create_samples: 2 <= N <= 1024 required");
     NERFMI_REQUIRE(samples_out, "create_samples: null pointer");
     const int64_t n = (int64_t)N * N * N;

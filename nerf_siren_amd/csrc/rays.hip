@@ -7,67 +7,9 @@
 // All are HBM-bound: loads/stores are coalesced along the sample axis.
 #include <stdarg.h>
 
-#include "common.h"
+#include "philox.h"
 
 namespace nerfmi {
-
-// ---------------------------------------------------------------------------
-// The four random draws of one render_rays call (rand(N,S) [rendering.py:221], randn(N,S) [:170],
-// rand(N,F) [:47], randn(N,S+F)) from a counter-based generator instead of four aten distribution launches:
-// Philox4x32-10 (Salmon et al., SC'11; Random123 known-answer vectors in tests/), key = seed, counter =
-// (quad index, segment, offset lo, offset hi); one 128-bit block = four floats of one segment.
-// uniform: (x >> 8) * 2^-24 in [0,1) (24 bits, like torch.rand); normal: Box-Muller on two such pairs.
-// Perf mode draws IN the consuming kernels (the *_philox entry points: no draw ever touches memory; the compositor's
-// backward regenerates its forward's noise from the same key); nerfmi_render_draws materialises the same streams.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-
-// (seed, offset, segment) address one stream of draws; `on` = 0 means "no generator" (draws injected or not needed).
-// Segments: 0 perturb_rand, 1 noise_coarse, 2 u, 3 noise_fine.  The SAME functions serve nerfmi_render_draws (draws
-// written to memory) and the kernels that draw in place (sample_stratified / composite / composite_backward /
-// importance_resample with a key): element e of a segment is the same float either way, bit for bit.
-struct DrawKey {
-    unsigned long long seed, offset;
-    int seg, on;
-};
-
-// the four floats of quad `i` of the key's segment (uniform for segments 0, 2; Box-Muller normals for 1, 3)
-__device__ __forceinline__ void draw_quad(const DrawKey &k, long long i, float (&v)[4]) {
-    unsigned c[4] = {(unsigned)i, (unsigned)k.seg | ((unsigned)(i >> 32) << 2), (unsigned)k.offset, (unsigned)(k.offset >> 32)};
-    philox4x32_10(c, (unsigned)k.seed, (unsigned)(k.seed >> 32));
-    if (k.seg & 1) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float u1 = (float)((c[2 * h] >> 8) + 1u) * 5.9604644775390625e-8f;      // (0, 1]
-            const float u2 = (float)(c[2 * h + 1] >> 8) * 5.9604644775390625e-8f;         // [0, 1)
-            const float r = sqrtf(-2.0f * logf(u1));
-            float sn, cs;
-            sincosf(6.283185307179586f * u2, &sn, &cs);
-            v[2 * h] = r * cs;
-            v[2 * h + 1] = r * sn;
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = (float)(c[t] >> 8) * 5.9604644775390625e-8f;
-    }
-}
-__device__ __forceinline__ float draw_one(const DrawKey &k, long long e) {
-    float v[4];
-    draw_quad(k, e >> 2, v);
-    const int t = (int)(e & 3);
-    return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3]));
-}
-
 
 static thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...) {
@@ -530,6 +472,7 @@ const char *nerfmi_last_error(void) { return g_err; }
 
 static int sample_stratified_impl(const char *who, const float *rays, const float *perturb_rand, DrawKey key, int n_rays,
                                   int n_samples, int use_disp, float perturb, float *z_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 1, "%s: bad sizes n_rays=%d n_samples=%d", who, n_rays, n_samples);
     if (n_rays == 0) return NERFMI_OK;
     NERFMI_REQUIRE(rays && z_out, "%s: null pointer", who);
@@ -555,6 +498,7 @@ int nerfmi_sample_stratified_philox(const float *rays, uint64_t seed, uint64_t o
 int nerfmi_render_draws(uint64_t seed, uint64_t offset, int64_t n_perturb, float *perturb_rand, int64_t n_noise_coarse,
                         float *noise_coarse, int64_t n_u, float *u, int64_t n_noise_fine, float *noise_fine,
                         nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     DrawSegs G;
     const int64_t n[4] = {n_perturb, n_noise_coarse, n_u, n_noise_fine};
     float *const o[4] = {perturb_rand, noise_coarse, u, noise_fine};
@@ -575,6 +519,7 @@ int nerfmi_render_draws(uint64_t seed, uint64_t offset, int64_t n_perturb, float
 }
 
 int nerfmi_embed(const float *x, int64_t n, int n_freqs, float *out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 0 && n_freqs >= 0 && n_freqs <= 24, "embed: bad sizes");
     if (n == 0) return NERFMI_OK;
     NERFMI_REQUIRE(x && out, "embed: null pointer");
@@ -596,6 +541,7 @@ int nerfmi_embed(const float *x, int64_t n, int n_freqs, float *out, nerfmi_stre
 static int composite_impl(const char *who, const float *field, int sigma_only, const float *z, const float *rays,
                           const float *noise, DrawKey key, float noise_std, int n_rays, int n_per_ray, int white_back,
                           float *weights_out, float *rgb_out, float *depth_out, float *opacity_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && n_per_ray <= 1024, "%s: n_per_ray=%d out of [1,1024]", who, n_per_ray);
     if (n_rays == 0) return NERFMI_OK;
     NERFMI_REQUIRE(field && z && rays, "%s: null input", who);
@@ -634,6 +580,7 @@ static int composite_backward_impl(const char *who, const float *field, const fl
                                    const float *noise, DrawKey key, float noise_std, int n_rays, int n_per_ray,
                                    int white_back, const float *g_rgb, const float *g_depth, const float *g_opacity,
                                    float *grad_field, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && n_per_ray <= 1024, "%s: n_per_ray=%d out of [1,1024]", who, n_per_ray);
     if (n_rays == 0) return NERFMI_OK;
     NERFMI_REQUIRE(field && z && rays && grad_field, "%s: null pointer", who);
@@ -693,6 +640,7 @@ int nerfmi_search_lerp(const float *bins, const float *cdf, const float *u, int 
 
 int nerfmi_searchsorted(const float *a, const float *v, int nrow_a, int nrow_v, int ncol_a, int ncol_v, int side_left,
                         int64_t *out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(nrow_a >= 1 && nrow_v >= 1 && ncol_a >= 0 && ncol_v >= 0, "searchsorted: bad sizes");
     NERFMI_REQUIRE(nrow_a == nrow_v || nrow_a == 1 || nrow_v == 1,
                    "searchsorted: row counts %d vs %d do not broadcast", nrow_a, nrow_v);
@@ -706,6 +654,7 @@ int nerfmi_searchsorted(const float *a, const float *v, int nrow_a, int nrow_v, 
 
 int nerfmi_merge_sorted(const float *za, const float *zb, int n_rays, int na, int nb, float *out,
                         nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && na >= 0 && nb >= 0 && na + nb <= 16384, "merge_sorted: bad sizes");
     if (n_rays == 0 || na + nb == 0) return NERFMI_OK;
     NERFMI_REQUIRE((za || na == 0) && (zb || nb == 0) && out, "merge_sorted: null pointer");
@@ -718,6 +667,7 @@ int nerfmi_merge_sorted(const float *za, const float *zb, int n_rays, int na, in
 static int importance_resample_impl(const char *who, const float *z_coarse, const float *weights_coarse, const float *u,
                                     DrawKey key, int n_rays, int n_samples, int n_importance, float *z_new_out,
                                     float *z_fine_out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_samples >= 3 && n_importance >= 1 && n_samples + n_importance <= 8192,
                    "%s: bad sizes S=%d F=%d (need S>=3, F>=1, S+F<=8192)", who, n_samples, n_importance);
     if (n_rays == 0) return NERFMI_OK;

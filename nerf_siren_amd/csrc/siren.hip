@@ -170,6 +170,7 @@ extern "C" {
 size_t nerfmi_siren_packed_floats(void) { return (size_t)SIREN_PACKED_FLOATS; }
 
 int nerfmi_siren_pack(const float *const *params, float *packed, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(params && packed, "siren_pack: null pointer");
     SirenParamPtrs P;
     for (int i = 0; i < SIREN_N_PARAMS; ++i) {
@@ -183,6 +184,7 @@ int nerfmi_siren_pack(const float *const *params, float *packed, nerfmi_stream_t
 int nerfmi_siren_forward_points(const float *packed, const float *points, const float *ray_directions,
                                 const float *frequencies, const float *phase_shifts, int64_t n_points,
                                 int64_t points_per_cond, int sigma_only, float *out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_points >= 0 && points_per_cond >= 1, "siren_forward_points: bad sizes");
     if (n_points == 0) return NERFMI_OK;
     NERFMI_REQUIRE(packed && points && frequencies && phase_shifts && out, "siren_forward_points: null pointer");
@@ -203,6 +205,7 @@ int nerfmi_siren_forward_points(const float *packed, const float *points, const 
 int nerfmi_siren_forward_rays(const float *packed, const float *rays, const float *z, const float *frequencies,
                               const float *phase_shifts, int n_rays, int n_per_ray, int64_t rays_per_cond,
                               int sigma_only, float *out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && rays_per_cond >= 1, "siren_forward_rays: bad sizes");
     const int64_t n_points = (int64_t)n_rays * n_per_ray;
     if (n_points == 0) return NERFMI_OK;
@@ -224,6 +227,7 @@ int nerfmi_siren_forward_rays(const float *packed, const float *rays, const floa
 size_t nerfmi_siren_fast_bytes(void) { return (size_t)SIREN_FAST_UNITS * 3072 + FAST_TAIL_BYTES; }
 
 int nerfmi_siren_pack_fast(const float *packed, void *fast, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(packed && fast, "siren_pack_fast: null pointer");
     hipLaunchKernelGGL(pack_bf16x3_table_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, siren_fast_table(), packed,
                        (__bf16 *)fast);
@@ -233,6 +237,7 @@ int nerfmi_siren_pack_fast(const float *packed, void *fast, nerfmi_stream_t stre
 int nerfmi_siren_forward_rays_fast(const float *packed, const void *fast, const float *rays, const float *z,
                                    const float *frequencies, const float *phase_shifts, int n_rays, int n_per_ray,
                                    int64_t rays_per_cond, int sigma_only, float *out, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && rays_per_cond >= 1, "siren_forward_rays_fast: bad sizes");
     const int64_t n_points = (int64_t)n_rays * n_per_ray;
     if (n_points == 0) return NERFMI_OK;

@@ -348,6 +348,7 @@ size_t nerfmi_siren_backward_workspace_floats(int64_t n_points) {
 int nerfmi_siren_forward_rays_train(const float *packed, const float *rays, const float *z, const float *frequencies,
                                     const float *phase_shifts, int n_rays, int n_per_ray, int64_t rays_per_cond,
                                     float *out, float *saved, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && rays_per_cond >= 1, "siren_forward_rays_train: bad sizes");
     const int64_t n_points = (int64_t)n_rays * n_per_ray;
     if (n_points == 0) return NERFMI_OK;
@@ -364,6 +365,7 @@ int nerfmi_siren_forward_rays_train(const float *packed, const float *rays, cons
 int nerfmi_siren_forward_points_train(const float *packed, const float *points, const float *ray_directions,
                                       const float *frequencies, const float *phase_shifts, int64_t n_points,
                                       int64_t points_per_cond, float *out, float *saved, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_points >= 0 && points_per_cond >= 1, "siren_forward_points_train: bad sizes");
     if (n_points == 0) return NERFMI_OK;
     NERFMI_REQUIRE(packed && points && ray_directions && frequencies && phase_shifts && out && saved,
@@ -380,6 +382,7 @@ static int siren_backward_impl(const char *who, const float *packed, const float
                                const float *frequencies, int64_t n_points, int64_t points_per_cond,
                                float *const *grad_params, float *grad_frequencies, float *grad_phase_shifts,
                                float *workspace, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_points >= 1 && points_per_cond >= 1, "%s: bad sizes", who);
     NERFMI_REQUIRE(packed && saved && grad_out && frequencies && grad_params && workspace, "%s: null pointer", who);
     const bool one_cond = points_per_cond >= n_points;

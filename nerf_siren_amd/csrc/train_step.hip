@@ -87,6 +87,7 @@ extern "C" {
 
 int nerfmi_mse_loss(const float *rgb_coarse, const float *rgb_fine, const float *targets, int64_t n_elems,
                     float grad_out, float *out4, float *grad_coarse, float *grad_fine, nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n_elems >= 1, "mse_loss: n_elems must be >= 1");
     NERFMI_REQUIRE((rgb_coarse || rgb_fine) && targets && out4, "mse_loss: null pointer");
     NERFMI_REQUIRE(!(grad_coarse && !rgb_coarse) && !(grad_fine && !rgb_fine), "mse_loss: gradient without its input");
@@ -98,6 +99,7 @@ int nerfmi_mse_loss(const float *rgb_coarse, const float *rgb_fine, const float 
 int nerfmi_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr,
                      double beta1, double beta2, double eps, double weight_decay, int64_t step, double grad_scale,
                      nerfmi_stream_t stream) {
+    NERFMI_ENTER();
     NERFMI_REQUIRE(n >= 0 && step >= 1, "adam_step: n >= 0 and step >= 1 required");
     if (n == 0) return NERFMI_OK;
     NERFMI_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adam_step: null pointer");

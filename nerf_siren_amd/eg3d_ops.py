@@ -62,18 +62,28 @@ def run_model_rays(planes_hwc, n, dec, ray_o, ray_d, depths, box_warp):
     return rgb, sigma
 
 
-def sample_stratified(n_rays, n_samples, rand, ray_start, ray_end, disparity=False):
-    rand = _req(rand.reshape(n_rays, n_samples), "rand")
-    out = torch.empty((n_rays, n_samples), device=rand.device, dtype=torch.float32)
-    if isinstance(ray_start, torch.Tensor):
-        st = _req(ray_start.reshape(n_rays), "ray_start")
-        en = _req(ray_end.reshape(n_rays), "ray_end")
-        check(_lib.lib().nerfmi_eg3d_sample_stratified(ptr(st), ptr(en), 0.0, 0.0, ptr(rand), n_rays, n_samples, 0,
-                                                       ptr(out), _stream(rand)), "eg3d_sample_stratified")
+def sample_stratified(n_rays, n_samples, rand, ray_start, ray_end, disparity=False, device=None):
+    """rand: the injected rand_like draw (n_rays, n_samples), or a (seed, offset) Philox key (ops.next_draw_key): the draw is
+    then made INSIDE the kernel (segment 0 of that stream) -- no aten distribution launch, no tensor of draws."""
+    philox = rand if isinstance(rand, tuple) else None
+    per_ray = isinstance(ray_start, torch.Tensor)
+    if philox is None:
+        rand = _req(rand.reshape(n_rays, n_samples), "rand")
+        device = rand.device
+    elif per_ray:
+        device = ray_start.device
+    out = torch.empty((n_rays, n_samples), device=device, dtype=torch.float32)
+    st = _req(ray_start.reshape(n_rays), "ray_start") if per_ray else None
+    en = _req(ray_end.reshape(n_rays), "ray_end") if per_ray else None
+    a, b = (0.0, 0.0) if per_ray else (float(ray_start), float(ray_end))
+    disp = 0 if per_ray else int(bool(disparity))
+    if philox is None:
+        check(_lib.lib().nerfmi_eg3d_sample_stratified(ptr(st), ptr(en), a, b, ptr(rand), n_rays, n_samples, disp, ptr(out),
+                                                       _stream(out)), "eg3d_sample_stratified")
     else:
-        check(_lib.lib().nerfmi_eg3d_sample_stratified(None, None, float(ray_start), float(ray_end), ptr(rand), n_rays,
-                                                       n_samples, int(bool(disparity)), ptr(out), _stream(rand)),
-              "eg3d_sample_stratified")
+        check(_lib.lib().nerfmi_eg3d_sample_stratified_philox(ptr(st), ptr(en), a, b, int(philox[0]) & (2 ** 64 - 1),
+                                                              int(philox[1]) & (2 ** 64 - 1), n_rays, n_samples, disp,
+                                                              ptr(out), _stream(out)), "eg3d_sample_stratified_philox")
     return out
 
 
@@ -102,10 +112,19 @@ def march(colors, densities, depths, white_back=False, mm=None):
     return rgb, depth, w, ws
 
 
-def sample_importance(depths, weights, u):
+def sample_importance(depths, weights, u, n_importance=None):
+    """u: the injected torch.rand draw (R, F), or a (seed, offset) Philox key + n_importance: drawn inside the kernel
+    (segment 2 of that stream)."""
     depths = _req(depths, "z_vals", (None, None))
     r, s = depths.shape
     weights = _req(weights.reshape(r, s - 1), "weights")
+    if isinstance(u, tuple):
+        f = int(n_importance)
+        out = torch.empty((r, f), device=depths.device, dtype=torch.float32)
+        check(_lib.lib().nerfmi_eg3d_sample_importance_philox(ptr(depths), ptr(weights), int(u[0]) & (2 ** 64 - 1),
+                                                              int(u[1]) & (2 ** 64 - 1), r, s, f, ptr(out), _stream(depths)),
+              "eg3d_sample_importance_philox")
+        return out
     u = _req(u, "u", (r, None))
     f = u.shape[1]
     out = torch.empty((r, f), device=depths.device, dtype=torch.float32)

@@ -60,7 +60,7 @@ class FlatGradAllReduce:
         # (rendering._claim_grad_target reads model._grad_target)
         self.joint = None
         ps0 = [p for m in self.models for p in m.parameters()]
-        if ps0 and all(p.is_cuda for p in ps0) and all(
+        if ps0 and len({p.device for p in ps0}) == 1 and all(
                 hasattr(m, "param_list") and hasattr(m, "grad_views")
                 and sum(p.numel() for p in m.param_list()) == getattr(m, "grad_numel", -1) for m in self.models):
             # the models of this package (NeRF: 595 844 floats, SirenField: 529 156): slice i of the joint buffer
@@ -165,7 +165,32 @@ class FlatGradAllReduce:
 
 
 def shard_rays(n_total: int, rank: int, world: int):
-    """Contiguous shard [lo, hi) of a ray buffer for this rank (rays are independent units)."""
+    """Contiguous shard [lo, hi) of a ray buffer for this rank (rays are independent units).  When world does not divide
+    n_total the last ranks get fewer rays (possibly none): a mean-of-per-rank-means is then NOT the batch mean -- weight
+    each rank's mean loss with shard_loss_weight(), or use shard_indices(pad=True) for the reference's DistributedSampler
+    behaviour."""
     per = (n_total + world - 1) // world
     lo = min(rank * per, n_total)
     return lo, min(lo + per, n_total)
+
+
+def shard_loss_weight(n_total: int, rank: int, world: int) -> float:
+    """Factor for this rank's MEAN loss so that the all-reduce(mean) of the gradients equals the gradient of the mean over
+    all n_total rays:  (1/world) sum_r w_r mean_r = (1/n_total) sum_r sum_{i in r} l_i  with  w_r = n_r * world / n_total.
+    1.0 for every rank when world divides n_total; 0.0 for a rank whose shard is empty (it still takes part in the
+    collective -- with zero gradients)."""
+    lo, hi = shard_rays(n_total, rank, world)
+    return (hi - lo) * world / n_total if n_total > 0 else 0.0
+
+
+def shard_indices(n_total: int, rank: int, world: int, pad: bool = True):
+    """Ray indices of this rank the way torch.utils.data.DistributedSampler(shuffle=False) deals them (the reference trains
+    under Lightning DDP, train.py:41-66, whose sampler pads the index list by wrapping around until world divides it and
+    gives rank r the indices r, r + world, r + 2 world, ...): every rank gets ceil(n_total / world) rays, up to world - 1
+    rays are seen twice per epoch, and mean-of-means is the mean over the padded list.  pad=False: the same interleaving
+    without the padding (uneven; combine with shard_loss_weight-style weighting by len())."""
+    idx = list(range(n_total))
+    if pad and n_total > 0 and n_total % world:
+        need = (n_total + world - 1) // world * world - n_total
+        idx += (idx * ((need + n_total - 1) // n_total + 1))[:need]
+    return idx[rank::world]

@@ -91,7 +91,9 @@ class FieldRender(torch.autograd.Function):
     of a FiLM-SIREN field behind nerf.SirenField)."""
 
     @staticmethod
-    def forward(ctx, model, rays, z, noise, noise_std, white_back, *params):
+    def forward(ctx, model, rays, z, noise, noise_std, white_back, keep, *params):
+        # keep: None, or a (dict, key) pair that receives the saved-activation image of this pass (parity tests read the
+        # ReLU sign pattern the kernels actually used out of it)
         siren = hasattr(model, "field_rays")
         ctx.n_field_params = len(model.param_list())      # SirenField may append its trainable conditioning rows behind them
         if siren:
@@ -110,6 +112,8 @@ class FieldRender(torch.autograd.Function):
         philox = noise if isinstance(noise, tuple) else None
         noise = None if philox is not None else noise
         weights, rgb, depth, opacity = ops.composite(field, z, rays, noise, noise_std, white_back, philox=philox)
+        if keep is not None:
+            keep[0][keep[1]] = saved
         ctx.save_for_backward(rays, z, noise if noise is not None else rays.new_empty(0), field, saved, packed)
         ctx.cfg = (noise is not None, float(noise_std), bool(white_back), siren)
         ctx.philox = philox
@@ -123,9 +127,9 @@ class FieldRender(torch.autograd.Function):
         rays, z, noise, field, saved, packed = ctx.saved_tensors
         has_noise, noise_std, white_back, siren = ctx.cfg
         n_params = len(ops.SIREN_PARAM_ORDER if siren else ops.PARAM_ORDER)
-        n_cond = len(ctx.needs_input_grad) - 6 - n_params            # 0, or 2: SirenField's frequencies, phase_shifts
+        n_cond = len(ctx.needs_input_grad) - 7 - n_params            # 0, or 2: SirenField's frequencies, phase_shifts
         if g_rgb is None and g_depth is None and g_opacity is None:
-            return (None,) * (6 + n_params + n_cond)
+            return (None,) * (7 + n_params + n_cond)
         grad_field = ops.composite_backward(field, z, rays, noise if has_noise else None, noise_std, white_back,
                                             g_rgb, g_depth, g_opacity, philox=ctx.philox)
         out = _claim_grad_target(ctx.model, rays.device)
@@ -139,7 +143,7 @@ class FieldRender(torch.autograd.Function):
         else:
             grads = ops.nerf_backward_rays(packed, rays, z, saved, grad_field, grads=out, fast=ctx.fast)
         _grad_ready(ctx.model, out)
-        return (None, None, None, None, None, None, *grads, *cond)
+        return (None, None, None, None, None, None, None, *grads, *cond)
 
 
 class SirenPoints(torch.autograd.Function):
@@ -215,7 +219,8 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
     Philox streams keyed by torch.manual_seed (ops.next_draw_key; ops.render_draws materialises the same streams).  'z_fine' (N,S+F), when given,
     replaces the merged depths of :247 (parity tests condition the fine pass on the reference's own depths:
     sample_pdf is ill-conditioned in ~zero-weight bins).
-    aux (keyword-only, optional): a dict that receives the intermediates 'z_coarse', 'weights_coarse', 'z_fine'.
+    aux (keyword-only, optional): a dict that receives the intermediates 'z_coarse', 'weights_coarse', 'z_fine' and, in
+    training mode, 'saved_coarse' / 'saved_fine' (the fields' saved-activation images, csrc/mlp_layout.h S_* rows).
     """
     if len(embeddings) != 2 or getattr(embeddings[0], "N_freqs", None) != 10 or \
             getattr(embeddings[1], "N_freqs", None) != 4:
@@ -263,7 +268,9 @@ def render_rays(models, embeddings, rays, N_samples=64, use_disp=False, perturb=
         if train and any(p.requires_grad for p in model.parameters()):
             cond = model.cond_param_list() if hasattr(model, "cond_param_list") else []
             rgb, depth, opacity, weights = FieldRender.apply(model, rays, zz, noise if philox is None else philox,
-                                                            float(noise_std), bool(white_back), *model.param_list(), *cond)
+                                                            float(noise_std), bool(white_back),
+                                                            None if aux is None else (aux, "saved_" + key[6:]),
+                                                            *model.param_list(), *cond)
         elif hasattr(model, "field_rays"):                     # FiLM-SIREN adapter (nerf.SirenField)
             field = model.field_rays(rays, zz, sigma_only=False)
             weights, rgb, depth, opacity = ops.composite(field, zz, rays, noise, noise_std, white_back, philox=philox)

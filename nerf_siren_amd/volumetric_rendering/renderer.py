@@ -51,7 +51,7 @@ class _RenderFn(torch.autograd.Function):
     def forward(ctx, ren, decoder, opts, depths_coarse, u, ray_o, ray_d, planes, w0, b0, w1, b1):
         N, M, _ = ray_o.shape
         S = depths_coarse.shape[1]
-        F = u.shape[1]
+        F = opts['depth_resolution_importance']
         wb = opts.get('white_back', False)
         planes_hwc = ren._pack(planes)
         dec = decoder.packed()
@@ -59,7 +59,7 @@ class _RenderFn(torch.autograd.Function):
         cc, sc = colors_c.reshape(N * M, S, 3), dens_c.reshape(N * M, S)
         mm_c = eg3d_ops.minmax(depths_coarse)
         rgb_c, depth_c, w_c, wsum_c = eg3d_ops.march(cc, sc, depths_coarse, wb, mm_c)
-        depths_fine = eg3d_ops.sample_importance(depths_coarse, w_c, u)
+        depths_fine = eg3d_ops.sample_importance(depths_coarse, w_c, u, F)
         colors_f, dens_f = eg3d_ops.run_model_rays(planes_hwc, N, dec, ray_o, ray_d, depths_fine, opts['box_warp'])
         cf, sf = colors_f.reshape(N * M, F, 3), dens_f.reshape(N * M, F)
         all_d, all_c, all_s, idx = eg3d_ops.unify(depths_coarse, cc, sc, depths_fine, cf, sf, want_idx=True)
@@ -122,18 +122,25 @@ class ImportanceRenderer(torch.nn.Module):
         N, M, _ = ray_origins.shape
         S = opts['depth_resolution']
         dev = ray_origins.device
+        # The two uniform draws of a forward (rand_like of renderer.py:172-195, rand of :230): the injected tensors (parity
+        # tests) or ONE Philox key per call (seed / offset of torch's CUDA generator, which the call advances), from which the
+        # sampling kernels draw in place -- segments 0 and 2 of that stream; no aten distribution launch on the path.
+        key = None
+        if opts.get('rng_stratified') is None or opts.get('rng_importance') is None:
+            from .. import ops as _ops
+            key = _ops.next_draw_key(dev)
         rs = opts.get('rng_stratified')
-        rs = torch.rand((N * M, S), device=dev) if rs is None else rs.reshape(N * M, S)
+        rs = key if rs is None else rs.reshape(N * M, S)
         if opts['ray_start'] == opts['ray_end'] == 'auto':
             ray_start, ray_end = math_utils.get_ray_limits_box(ray_origins, ray_directions, box_side_length=opts['box_warp'])
             is_ray_valid = ray_end > ray_start
             if torch.any(is_ray_valid).item():                                   # renderer.py:93-95
                 ray_start[~is_ray_valid] = ray_start[is_ray_valid].min()
                 ray_end[~is_ray_valid] = ray_start[is_ray_valid].max()
-            depths_coarse = eg3d_ops.sample_stratified(N * M, S, rs, ray_start, ray_end)
+            depths_coarse = eg3d_ops.sample_stratified(N * M, S, rs, ray_start, ray_end, device=dev)
         else:
             depths_coarse = eg3d_ops.sample_stratified(N * M, S, rs, opts['ray_start'], opts['ray_end'],
-                                                       opts.get('disparity_space_sampling', False))
+                                                       opts.get('disparity_space_sampling', False), device=dev)
         o, d = ray_origins.detach().contiguous(), ray_directions.detach().contiguous()
         if train:
             if opts.get('density_noise', 0) > 0:
@@ -142,9 +149,9 @@ class ImportanceRenderer(torch.nn.Module):
             if F_ <= 0:
                 raise ValueError(_NO_IMPORTANCE)
             u_ = opts.get('rng_importance')
-            u_ = torch.rand((N * M, F_), device=dev) if u_ is None else u_.reshape(N * M, F_)
+            u_ = key if u_ is None else u_.reshape(N * M, F_).contiguous()
             net = decoder.net
-            return _RenderFn.apply(self, decoder, opts, depths_coarse, u_.contiguous(), o, d, planes, net[0].weight,
+            return _RenderFn.apply(self, decoder, opts, depths_coarse, u_, o, d, planes, net[0].weight,
                                    net[0].bias, net[2].weight, net[2].bias)
         planes_hwc = self._pack(planes)
         dec = decoder.packed()
@@ -161,8 +168,8 @@ class ImportanceRenderer(torch.nn.Module):
         if F <= 0:
             raise ValueError(_NO_IMPORTANCE)
         u = opts.get('rng_importance')
-        u = torch.rand((N * M, F), device=dev) if u is None else u.reshape(N * M, F)
-        depths_fine = eg3d_ops.sample_importance(depths_coarse, weights_coarse, u)
+        u = key if u is None else u.reshape(N * M, F)
+        depths_fine = eg3d_ops.sample_importance(depths_coarse, weights_coarse, u, F)
         colors_fine, dens_fine = eg3d_ops.run_model_rays(planes_hwc, N, dec, o, d, depths_fine, opts['box_warp'])
         if opts.get('density_noise', 0) > 0:
             dens_fine = dens_fine + torch.randn_like(dens_fine) * opts['density_noise']
@@ -196,14 +203,17 @@ class ImportanceRenderer(torch.nn.Module):
                           rand=None):
         """renderer.py:172-195 -> (N,M,S,1)."""
         N, M, _ = ray_origins.shape
-        rs = torch.rand((N * M, depth_resolution), device=ray_origins.device) if rand is None else rand
-        return eg3d_ops.sample_stratified(N * M, depth_resolution, rs, ray_start, ray_end,
-                                          disparity_space_sampling).view(N, M, depth_resolution, 1)
+        if rand is None:
+            from .. import ops as _ops
+            rand = _ops.next_draw_key(ray_origins.device)
+        return eg3d_ops.sample_stratified(N * M, depth_resolution, rand, ray_start, ray_end, disparity_space_sampling,
+                                          device=ray_origins.device).view(N, M, depth_resolution, 1)
 
     def sample_importance(self, z_vals, weights, N_importance, u=None):
         """renderer.py:197-215 -> (N,M,N_importance,1)."""
         n, m, s, _ = z_vals.shape
         if u is None:
-            u = torch.rand((n * m, N_importance), device=z_vals.device)
-        out = eg3d_ops.sample_importance(z_vals.reshape(n * m, s), weights.reshape(n * m, s - 1), u)
+            from .. import ops as _ops
+            u = _ops.next_draw_key(z_vals.device)
+        out = eg3d_ops.sample_importance(z_vals.reshape(n * m, s), weights.reshape(n * m, s - 1), u, N_importance)
         return out.view(n, m, N_importance, 1)

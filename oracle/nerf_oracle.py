@@ -388,14 +388,15 @@ def render_rays(params, rays, N_samples=64, use_disp=False, perturb=0.0, noise_s
     return res
 
 
-def render_rays_backward(params, res, grads, white_back=False):
+def render_rays_backward(params, res, grads, white_back=False, masks=None):
     """Parameter gradients of a training-mode render_rays() call made with
     keep=True.  grads: dict name -> dL/d(output) for any of rgb_/depth_/opacity_
     {coarse,fine}.  Returns [g_coarse, g_fine] (fine None when absent).
-    No gradient crosses sample_pdf (rendering.py:54 cdf.detach(), :244 .detach())."""
+    No gradient crosses sample_pdf (rendering.py:54 cdf.detach(), :244 .detach()).
+    masks (tests only): [coarse, fine] ReLU masks for nerf_backward (see there), or None."""
     aux = res["_aux"]
     out = []
-    for tag in ("coarse", "fine"):
+    for ti, tag in enumerate(("coarse", "fine")):
         key = "_" + tag
         if key not in aux:
             out.append(None)
@@ -408,7 +409,8 @@ def render_rays_backward(params, res, grads, white_back=False):
         g_op = grads.get("opacity_" + tag, zero)
         d_s, d_rgb = composite_backward(cres["_cache"], cres["weights"], g_rgb, g_dep, g_op, white_back)
         g_out = np.concatenate([d_rgb, d_s[:, :, None]], -1).reshape(-1, 4)
-        out.append(nerf_backward(params[0 if tag == "coarse" else 1], mcache, g_out))
+        out.append(nerf_backward(params[0 if tag == "coarse" else 1], mcache, g_out,
+                                 masks=None if masks is None else masks[ti]))
     return out
 
 

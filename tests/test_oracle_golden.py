@@ -180,30 +180,38 @@ GRAD_CASES = ["blender_train", "ndc_train", "blender_disp", "coarse_only", "odd_
 
 @pytest.mark.parametrize("case", GRAD_CASES)
 def test_render_rays_gradients(golden, case):
-    """Manual backward of the oracle == autograd of the reference.
+    """Manual backward of the oracle == autograd of the reference, per tensor, to 1e-4 relative (typical 1e-6).
 
-    Typical agreement is 1e-6 relative; the bound is 5e-3 because a ReLU whose
-    pre-activation is ~0 can land on either side under a different fp32 GEMM
-    summation order (MKL vs OpenBLAS here), which switches that unit's whole
-    gradient path on or off (seen in blender_disp: layers <= 6 at 1e-3).
-    Fine-model gradients additionally inherit sample_pdf's ill-conditioning (a
-    1-ulp cdf change moves samples in ~zero-weight bins): 2e-2 end to end, 5e-3
-    once conditioned on the reference's own merged depths (rng['z_fine'])."""
-    g = golden("g7_" + case)
+    Rounds 1-2 allowed 5e-3 / 2e-2 here because (a) a ReLU whose pre-activation is ~0 lands on either side of the kink
+    under a different fp32 GEMM summation order (MKL vs OpenBLAS), which switches that unit's gradient path, and (b) the
+    fine model inherits sample_pdf's ill-conditioning.  Round 3 removes both causes instead of absorbing them: (a) the
+    fixture stores the sign pattern the REFERENCE used for every unit within 1e-4 of the kink (tests/kinks.py) and the
+    oracle's backward is evaluated with exactly that pattern -- the units that took the other side are counted (0..3 per
+    case) and nothing else is exempted; (b) the fine pass runs on the reference's own merged depths (rng['z_fine'])."""
+    import kinks
+    g = dict(golden("g7_" + case))
+    if int(g["F"]) > 0:
+        g["rng_z_fine"] = g["mid_sort_out"]
     params, res = run_oracle_case(g, keep=True)
-    gs = O.render_rays_backward(params, res, _loss_grads(g, res), bool(g["white_back"]))
+    masks, flips = [], 0
+    for mi, tag in enumerate(("coarse", "fine")[: 2 if int(g["F"]) > 0 else 1]):
+        m, f = kinks.reference_masks(g, mi, res["_aux"]["_" + tag][0])
+        masks.append(m)
+        flips += f
+    if len(masks) == 1:
+        masks.append(None)
+    gs = O.render_rays_backward(params, res, _loss_grads(g, res), bool(g["white_back"]), masks=masks)
     w = grad_rel_errors(g, gs)
-    assert w[0] < 5e-3, w
-    if len(w) > 1:
-        assert w[1] < 2e-2, w
-        g2 = dict(g)
-        g2["rng_z_fine"] = g["mid_sort_out"]
-        params, res = run_oracle_case(g2, keep=True)
-        gs = O.render_rays_backward(params, res, _loss_grads(g, res), bool(g["white_back"]))
-        w = grad_rel_errors(g, gs)
-        assert w[0] < 5e-3 and w[1] < 5e-3, w
+    print(f"[{case}] units on the other side of the kink in the reference: {flips}; worst relative gradient error {max(w):.2e}")
+    assert flips <= 8, flips
+    assert max(w) < 1e-4, w
+    if int(g["F"]) > 0:
         for k in ("rgb_fine", "depth_fine", "opacity_fine"):
             assert np.abs(res[k] - g["out_" + k]).max() < 3e-6, k
+    # ... and with its OWN pattern the oracle differs from the reference by exactly the flipped units' paths: no flip -> 1e-4
+    if flips == 0:
+        w0 = grad_rel_errors(g, O.render_rays_backward(params, res, _loss_grads(g, res), bool(g["white_back"])))
+        assert max(w0) < 1e-4, w0
 
 
 def test_siren_oracle_vs_reference(golden):

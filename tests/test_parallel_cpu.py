@@ -1,5 +1,5 @@
-"""world_size-2 gloo test of the data-parallel glue (runs on CPU): sharded rays +
-flat-gradient all-reduce(mean) == single-process gradient of the mean loss."""
+"""gloo tests of the data-parallel glue (run on CPU; world 2 and 8): sharded rays + flat-gradient all-reduce(mean) ==
+single-process gradient of the mean loss, for ray counts the world does and does not divide."""
 import os
 import socket
 
@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from nerf_siren_amd.parallel import FlatGradAllReduce, shard_rays
+from nerf_siren_amd.parallel import FlatGradAllReduce, shard_indices, shard_loss_weight, shard_rays
 
 
 def _free_port():
@@ -77,6 +77,91 @@ def test_flat_grad_allreduce_matches_single_process():
     assert torch.equal(got[0], got[1])
 
 
+def _worker_uneven(rank, world, port, q, n, mode):
+    """mode 'weight': contiguous uneven shards, each rank's mean loss weighted by shard_loss_weight (== the batch mean);
+    mode 'pad': DistributedSampler semantics (wrap-around padding, == the mean over the padded index list)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    torch.manual_seed(1)
+    rays = torch.randn(n, 8)
+    models = _models()
+    red = FlatGradAllReduce(models, world)
+    red.zero_()
+    if mode == "weight":
+        lo, hi = shard_rays(n, rank, world)
+        if hi > lo:
+            (_loss(models, rays[lo:hi]) * shard_loss_weight(n, rank, world)).backward()
+        else:                                                     # an empty shard still takes part in the collective
+            for m in models:
+                for p in m.parameters():
+                    p.grad = torch.zeros_like(p)
+    else:
+        _loss(models, rays[shard_indices(n, rank, world)]).backward()
+    red.all_reduce()
+    q.put((rank, torch.cat([p.grad.reshape(-1) for m in models for p in m.parameters()])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world(target, world, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,n", [(8, 64), (8, 61), (2, 13), (8, 5)])
+def test_uneven_and_eight_rank_shards(world, n):
+    """Round-2 verdict (weak #8): parallel.shard_rays gives the last rank fewer rays when world does not divide n, and
+    mean-of-per-rank-means then differs from the batch mean.  Both remedies, at world 2 and at world 8 (eight gloo ranks on
+    the CPU; (8, 5) leaves three ranks with EMPTY shards): (a) weighting each rank's mean loss by shard_loss_weight
+    reproduces the single-process gradient of the mean over all n rays; (b) shard_indices(pad=True) reproduces what the
+    reference's Lightning DDP does (DistributedSampler wrap-around padding): the mean over the padded index list."""
+    def single(idx):
+        torch.manual_seed(1)
+        rays = torch.randn(n, 8)
+        models = _models()
+        _loss(models, rays[idx]).backward()
+        return torch.cat([p.grad.reshape(-1) for m in models for p in m.parameters()])
+    got = _run_world(_worker_uneven, world, n, "weight")
+    ref = single(list(range(n)))
+    for r in range(world):
+        assert torch.allclose(got[r], ref, atol=2e-6), (r, float((got[r] - ref).abs().max()))
+        assert torch.equal(got[r], got[0])                       # replicas stay identical
+    got = _run_world(_worker_uneven, world, n, "pad")
+    padded = [i for r in range(world) for i in shard_indices(n, r, world)]
+    assert len(padded) == -(-n // world) * world
+    ref = single(padded)
+    for r in range(world):
+        assert torch.allclose(got[r], ref, atol=2e-6), (r, float((got[r] - ref).abs().max()))
+
+
+def test_shard_weights_and_padding():
+    from torch.utils.data import DistributedSampler
+
+    class _DS:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+    for n, w in ((10, 3), (1023, 8), (5, 8), (64, 8), (8192, 8)):
+        assert abs(sum(shard_loss_weight(n, r, w) for r in range(w)) - w) < 1e-9
+        for r in range(w):
+            assert list(DistributedSampler(_DS(n), num_replicas=w, rank=r, shuffle=False)) == shard_indices(n, r, w)
+    assert all(shard_loss_weight(8192, r, 8) == 1.0 for r in range(8))
+
+
 def test_shard_rays_partition():
     for n, w in ((1024, 8), (10, 3), (5, 8), (0, 2)):
         spans = [shard_rays(n, r, w) for r in range(w)]
@@ -91,6 +176,11 @@ class _ToyModel(torch.nn.Module):
         super().__init__()
         self.w = torch.nn.Parameter(torch.tensor([1.0, 2.0, 3.0, 4.0]))
         self._grad_target = torch.zeros(4)
+
+    grad_numel = 4
+
+    def param_list(self):
+        return [self.w]
 
     def grad_views(self, flat):
         return [flat[0:4]]
@@ -131,3 +221,22 @@ def test_grad_target_is_claimed_once_per_backward_pass():
     # accumulation across passes (grad not cleared, still aliasing the target): must add, not overwrite
     _ToyRender.apply(m, 5.0, m.w).backward()
     assert torch.equal(m.w.grad, torch.full((4,), 8.0))
+
+
+def test_reducer_replacement_and_failed_backward():
+    """Round-2 advisor findings on FlatGradAllReduce: (1) a later non-overlapping reducer built over the same models must
+    disarm the earlier reducer's grad-ready hook (it used to stay live and launch collectives into the stale reducer);
+    (2) a backward pass that dies after the target was claimed / a collective launched must not poison the next step --
+    zero_() / reset() is the step boundary that clears both."""
+    m = _ToyModel()
+    first = FlatGradAllReduce([m], world_size=2, overlap=True)
+    assert first.overlap and m._grad_ready_hook is not None
+    second = FlatGradAllReduce([m], world_size=1)
+    assert m._grad_ready_hook is None and not second.overlap      # the model belongs to the LAST reducer built over it
+    # a pass that raises after the claim: the engine callback that releases the claim never runs
+    m._grad_target_claimed = True
+    second._works = {0: type("W", (), {"wait": staticmethod(lambda: None)})()}
+    second.zero_()
+    assert not m._grad_target_claimed and second._works == {}
+    _ToyRender.apply(m, 2.0, m.w).backward()
+    assert torch.equal(m.w.grad, torch.full((4,), 2.0))
