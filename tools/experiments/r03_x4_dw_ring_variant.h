@@ -1,0 +1,381 @@
+// dW = dZ^T . X over points (a GEMM whose contraction runs over POINTS) and its deterministic slab reduction, shared
+// by the NeRF backward (mlp_bwd.hip) and the FiLM-SIREN backward (siren_bwd.hip).  Both operands are tile-major images
+// (mlp_core.h RowImage): A = rows of the backward workspace (AROWS rows per tile), B = rows of the saved activations
+// (BROWS rows per tile).
+#pragma once
+#include "/root/repo/nerf_siren_amd/csrc/mlp_core.h"
+
+namespace nerfmi {
+
+struct DwTask {
+    int kind;       // template instance 0..5
+    int a_row0;     // first dZ row in the workspace
+    int a_valid;    // real rows (others read as 0)
+    int b_row0;     // first X row in the saved image
+    int b_valid;
+    int param;      // weight tensor index
+    int out_col0;   // first column of the weight this task covers
+    int in_f;       // row stride of the weight tensor
+    int bias_param; // bias tensor index or -1
+    int chunks;     // split of the point range = number of partial slabs
+    int wp;         // dw_task4: slabs per workgroup (the tile's points split over two wave pairs); 1 otherwise
+    int wg0;        // first workgroup of this task
+    int part_off;   // float offset of this task's slabs in the partial buffer
+    int JB, KB;     // block counts (rows/cols of the slab = 32*JB x 32*KB)
+};
+constexpr int MAX_TASKS = 16;
+struct DwPlan {
+    DwTask t[MAX_TASKS];
+    int n_tasks;
+    int n_wg;
+};
+
+constexpr int LROW = 36;   // LDS row pitch in floats: 32 points + 4 pad (conflict-free ds_read_b128)
+
+template <int JW, int KW, int WJ, int WK, int AROWS, int BROWS>
+__device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float *__restrict__ work,
+                                        const float *__restrict__ saved, int64_t ld, float *__restrict__ partial,
+                                        float *lds) {
+    constexpr int JB = JW * WJ, KB = KW * WK;
+    constexpr int ROWS = (JB + KB) * 32;
+    constexpr int NLD = JB + KB;              // staging slots per thread: slot i = rows 32i..32i+31 (A blocks, then B)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
+    const int wj = wid / WK, wk = wid % WK;
+    const int64_t tiles = ld / 32;
+    const int64_t t_lo = tiles * chunk / T.chunks, t_hi = tiles * (chunk + 1) / T.chunks;
+
+    // Inside a tile the rows of an image are contiguous (128 B each): thread (srow, c4) of slot i fetches float4
+    // c4 of row 32i + srow, so one wave-load is 1 KiB contiguous.  The per-thread part of every address (global
+    // and LDS) is the SAME for all slots and all tiles; the slot and tile parts are wave-uniform and live in
+    // scalar registers / immediate offsets.  That matters because fp32 MFMAs do not overlap with the wave's own
+    // vector instructions (tools/ubench/mfma_valu.hip): address arithmetic in the loop is paid in matrix-pipe time.
+    // Rows past the real operand (the 3 + 1 rows of the heads' dZ) are read as whatever follows them in the image
+    // -- at worst the dump tile behind the last real one (mlp_core.h RowImage): an MFMA output row depends on its own
+    // A row only, and the reduce kernel never reads the slab rows >= a_valid.  The padded B rows (row 63 of the
+    // xyz embedding, 27..31 of the direction embedding) are stored as zeros by the forward.
+    const int srow = tid >> 3, c4 = tid & 7;
+    const unsigned voff = (unsigned)(srow * 32 + 4 * c4);             // floats, global
+    const unsigned loff = (unsigned)(srow * LROW + 4 * c4);           // floats, LDS
+    const float *abase = work + (int64_t)T.a_row0 * 32;
+    const float *bbase = saved + (int64_t)T.b_row0 * 32;
+
+    f32x16 acc[JW][KW];
+#pragma unroll
+    for (int a = 0; a < JW; ++a)
+#pragma unroll
+        for (int b = 0; b < KW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[JW];
+#pragma unroll
+    for (int a = 0; a < JW; ++a) bsum[a] = 0.f;
+
+    f32x4 stage[NLD];
+    auto load_slot = [&](int i, int64_t t) {
+        const float *src = (i < JB) ? abase + t * (int64_t)(AROWS * 32) + i * 1024
+                                    : bbase + t * (int64_t)(BROWS * 32) + (i - JB) * 1024;     // wave-uniform
+#ifdef NERFMI_EXP_DW_TLOAD
+        stage[i] = ldg4(src + voff);
+#else
+        // streamed exactly once by exactly one workgroup: non-temporal, so the 2.7 GB of dZ / X tiles do not sweep L2
+        stage[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + voff));
+#endif
+    };
+    auto write_slot = [&](int i, float *buf) {
+        *reinterpret_cast<f32x4 *>(buf + i * (32 * LROW) + loff) = stage[i];
+    };
+    // Double-buffered LDS, ONE barrier per tile: at the top of iteration t the registers hold tile t+1
+    // (loaded during iteration t-1); it is written into the other buffer (last read in iteration t-1, which
+    // every wave left through the barrier), tile t+2's loads are issued, then tile t is consumed.
+    float *buf0 = lds, *buf1 = lds + ROWS * LROW;
+    if (t_lo < t_hi) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) load_slot(i, t_lo);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) write_slot(i, buf0);
+        if (t_lo + 1 < t_hi) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) load_slot(i, t_lo + 1);
+        }
+    }
+    __syncthreads();
+    // one tile: consume `cur`, stage tile t+1 into `nxt` and reload the registers with tile t+2 -- the staging of
+    // slot i sits after MFMA group i*(groups/NLD), spread over the tile's MFMA stream instead of in front of it.
+    // Past the end the (clamped) tile is staged redundantly, which keeps the body branch-free.
+    auto tile = [&](int64_t t, const float *cur, float *nxt) __attribute__((always_inline)) {
+        const int64_t t2 = (t + 2 < t_hi) ? t + 2 : t_hi - 1;
+        const float *arow = cur + (32 * (wj * JW) + (lane & 31)) * LROW + 4 * half;
+        const float *brow = cur + (32 * (JB + wk * KW) + (lane & 31)) * LROW + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a[JW], b[KW];
+#pragma unroll
+            for (int x = 0; x < JW; ++x) a[x] = *reinterpret_cast<const f32x4 *>(arow + x * (32 * LROW) + 8 * q);
+#pragma unroll
+            for (int x = 0; x < KW; ++x) b[x] = *reinterpret_cast<const f32x4 *>(brow + x * (32 * LROW) + 8 * q);
+#pragma unroll
+            for (int x = 0; x < JW; ++x) bsum[x] += (a[x][0] + a[x][1]) + (a[x][2] + a[x][3]);
+#pragma unroll
+            for (int x = 0; x < JW; ++x)
+#pragma unroll
+                for (int y = 0; y < KW; ++y) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x][s], b[y][s], acc[x][y], 0, 0, 0);
+                    constexpr int NG = 4 * JW * KW;                       // MFMA groups per tile
+                    const int gidx = (q * JW + x) * KW + y;
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i)
+                        if (gidx == (i * NG) / NLD) {
+                            write_slot(i, nxt);
+                            load_slot(i, t2);
+                        }
+                }
+        }
+        __syncthreads();
+    };
+    // two tiles per trip, so that which buffer is read and which is written is static inside the body
+    for (int64_t t = t_lo; t < t_hi; t += 2) {
+        tile(t, buf0, buf1);
+        if (t + 1 < t_hi) tile(t + 1, buf1, buf0);
+    }
+    // partial slab [chunk][32*JB][32*KB] then bias slab [chunk][32*JB]
+    float *slab = partial + T.part_off + (int64_t)chunk * (JB * 32 * (KB * 32 + 1));
+#pragma unroll
+    for (int x = 0; x < JW; ++x)
+#pragma unroll
+        for (int y = 0; y < KW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * (wj * JW + x) + 8 * (r >> 2) + 4 * half + (r & 3);
+                const int k = 32 * (wk * KW + y) + (lane & 31);
+                slab[j * (KB * 32) + k] = acc[x][y][r];
+            }
+    if (wk == 0) {
+#pragma unroll
+        for (int x = 0; x < JW; ++x) {
+            const float s = bsum[x] + __shfl_xor(bsum[x], 32, WAVE);
+            if (half == 0) slab[JB * 32 * KB * 32 + 32 * (wj * JW + x) + lane] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dW on the "x4" images of the FiLM-SIREN training path (round 3).
+//
+// Layout: element (row r, point p) of a 32-point tile lives at  tile + ((r >> 2) * 32 + p) * 4 + (r & 3):  the four rows of a
+// ROW GROUP are interleaved per point.  In the MLP kernels a lane owns four consecutive units of one point (registers 4q..4q+3
+// of an accumulator block), so a slice of a saved / dZ image is ONE 16-byte store (one 1 KiB wave-store) where the
+// [row][32 points] layout needs four 4-byte stores, and the chain kernel reads the saved sines back with one 16-byte load
+// per slice instead of four -- a vector-memory instruction costs the same issue slot and TA time whatever its width
+// (tools/ubench/pk_valu.hip: global_store_dword and _dwordx4 both ~100 cycles apiece back to back, profiles/r03_ubench_pk_valu.txt).
+//
+// Rounds 1-2 did not take that layout because "the dW GEMM would need a transposing staging".  It does not: the rows of an
+// MFMA operand may be ANY 32 rows.  A lane reads one 16-byte LDS word = (row group g = its lane & 31, point 2s + (lane >> 5))
+// = the four units 4g..4g+3 of one point, and feeds unit i of it to MFMA i: operand A_i is "unit i of 32 consecutive row
+// groups" (rows 4g + i), B_j likewise, and the 4 x 4 products A_i (x) B_j fill a 128 x 128 tile of dW whose rows / columns are
+// merely interleaved (row 4m + i of the tile sits in accumulator (i, .) row m) -- undone for free when the slab is written.
+// Per 32-point tile a wave issues 2 LDS reads per 16 MFMAs (the [row][point] kernel above: 10 per 16).
+//   kind 0  256 x 256 : IA = 4, JB4 = 4, waves 2 (A sets) x 2 (B sets)
+//   kind 1  256 x 3   : the three input columns sit in unit 0 of row groups 0..2 (rows 0, 4, 8): IA = 4, JB4 = 1; waves
+//                       2 (A sets) x 2 (halves of the tile's points, written as two slabs: the reduction sums slabs anyway)
+//   kind 2  3 x 256   : the head's dZ rows sit in unit 0 of row groups 0..2: IA = 1, JB4 = 4; waves 2 (B sets) x 2 (point halves)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int G4PITCH = 132;   // LDS floats per row group: 32 points x 4 units + 4 pad (16 lanes x 16 B land on 64 distinct banks)
+
+template <int IA, int JB4, int WA, int WB, int WP, int AROWS, int BROWS>
+__device__ __forceinline__ void dw_task4(const DwTask &T, int chunk, const float *__restrict__ work,
+                                         const float *__restrict__ saved, int64_t ld, float *__restrict__ partial,
+                                         float *lds) {
+    static_assert(WA * WB * WP == 4, "four waves per workgroup");
+    constexpr int NA_RG = (IA == 4) ? WA * 32 : 8;        // row groups staged per tile (8 = one 4 KiB slot: the narrow operand)
+    constexpr int NB_RG = (JB4 == 4) ? WB * 32 : 8;
+    constexpr int A_ALLOC = NA_RG < 32 ? 32 : NA_RG;      // a wave's 32 lanes read 32 row groups: keep the reads inside LDS
+    constexpr int B_ALLOC = NB_RG < 32 ? 32 : NB_RG;
+    constexpr int NLD = (NA_RG + NB_RG) / 8;              // staging slots of 8 row groups (256 threads x 16 B)
+    constexpr int BUF = (A_ALLOC + B_ALLOC) * G4PITCH;
+    constexpr int STEPS = 16 / WP;                        // k-steps (point pairs) of a tile that this wave multiplies
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5;
+    const int wa = wid % WA, wb = (wid / WA) % WB, wp = wid / (WA * WB);
+    const int wg_chunks = T.chunks / WP;                  // workgroups of this task (T.chunks counts slabs)
+    const int64_t tiles = ld / 32;
+    const int64_t t_lo = tiles * chunk / wg_chunks, t_hi = tiles * (chunk + 1) / wg_chunks;
+    // thread (row group tid >> 5 of the slot, point tid & 31): global offset tid * 4 floats inside the slot's 4 KiB
+    const unsigned voff = (unsigned)tid * 4;
+    const unsigned loff = (unsigned)((tid >> 5) * G4PITCH + (tid & 31) * 4);
+    const float *abase = work + (int64_t)T.a_row0 * 32;
+    const float *bbase = saved + (int64_t)T.b_row0 * 32;
+
+    f32x16 acc[IA][JB4];
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+#pragma unroll
+        for (int j = 0; j < JB4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[IA];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) bsum[i] = 0.f;
+
+    // Staging ring: the next tile goes global -> registers -> LDS slot by slot WHILE the current tile is multiplied; a slot's
+    // registers live for RING steps only (not for a whole tile: sixteen 16-byte slots held across the tile were 64 VGPRs that
+    // the allocator spilled to scratch and reloaded inside the MFMA loop).  Step s of tile t writes slot s of tile t+1 into
+    // the other LDS buffer and reuses its registers for the slot RING steps ahead (of tile t+1, or of tile t+2 past the end).
+    constexpr int RING = NLD < 8 ? NLD : 8;
+    f32x4 ring[RING];
+    auto load_slot = [&](int i, int64_t t, int r) {
+        const float *src = (i < NA_RG / 8) ? abase + t * (int64_t)(AROWS * 32) + i * 1024
+                                           : bbase + t * (int64_t)(BROWS * 32) + (i - NA_RG / 8) * 1024;   // wave-uniform
+        ring[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + voff));   // streamed exactly once
+    };
+    // `wbase` = this thread's LDS write address inside the destination buffer, laundered through an empty asm once per tile:
+    // the slot offsets (compile-time constants < 64 KiB) then stay immediates of ds_write_b128.  Without that the compiler
+    // hoists one full address per slot and buffer out of the tile loop -- 32 VGPRs that it then spilled to scratch, each
+    // reload followed by an s_waitcnt vmcnt(0) that also drained the global loads in flight.
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    auto write_slot = [&](int i, unsigned wbase, int r) {
+        const unsigned off = ((i < NA_RG / 8) ? (8 * i) * G4PITCH : (A_ALLOC + 8 * (i - NA_RG / 8)) * G4PITCH) * 4u;
+        *reinterpret_cast<lds_f32x4 *>(wbase + off) = ring[r];
+    };
+    auto lds_addr = [&](const float *p) {
+        unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p + loff * 4u;
+        asm volatile("" : "+v"(a));
+        return a;
+    };
+    float *buf0 = lds, *buf1 = lds + BUF;
+    auto clampt = [&](int64_t t) { return t < t_hi ? t : t_hi - 1; };
+    if (t_lo < t_hi) {
+        // tile t_lo straight into buf0 (RING slots at a time), then the first RING slots of tile t_lo + 1 into the ring
+#pragma unroll
+        for (int i0 = 0; i0 < NLD; i0 += RING) {
+#pragma unroll
+            for (int r = 0; r < RING; ++r)
+                if (i0 + r < NLD) load_slot(i0 + r, t_lo, r);
+#pragma unroll
+            for (int r = 0; r < RING; ++r)
+                if (i0 + r < NLD) write_slot(i0 + r, lds_addr(buf0), r);
+        }
+#pragma unroll
+        for (int r = 0; r < RING; ++r) load_slot(r, clampt(t_lo + 1), r);
+    }
+    __syncthreads();
+    // slot i of the next tile is written at step W(i) = i * STEPS / NLD; one barrier per tile
+    auto tile = [&](int64_t t, const float *cur, float *nxt) __attribute__((always_inline)) {
+        const int64_t t1 = clampt(t + 1), t2 = clampt(t + 2);
+        const unsigned wb_ = lds_addr(nxt);
+        const float *arow = cur + (((IA == 4) ? wa * 32 : 0) + (lane & 31)) * G4PITCH + 4 * half;
+        const float *brow = cur + (A_ALLOC + ((JB4 == 4) ? wb * 32 : 0) + (lane & 31)) * G4PITCH + 4 * half;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int ks = STEPS * wp + s;                                  // point pair 2 ks, 2 ks + 1
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(arow + 8 * ks);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(brow + 8 * ks);
+#pragma unroll
+            for (int i = 0; i < IA; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[i]) : "v"(a[i]));
+#pragma unroll
+            for (int i = 0; i < IA; ++i)
+#pragma unroll
+                for (int j = 0; j < JB4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                if (s == (i * STEPS) / NLD) {
+                    write_slot(i, wb_, i % RING);
+                    if (i + RING < NLD) load_slot(i + RING, t1, i % RING);
+                    else load_slot(i + RING - NLD, t2, i % RING);
+                }
+        }
+        __syncthreads();
+    };
+    for (int64_t t = t_lo; t < t_hi; t += 2) {
+        tile(t, buf0, buf1);
+        if (t + 1 < t_hi) tile(t + 1, buf1, buf0);
+    }
+    // slab [32*JB rows][32*KB cols] then the bias slab [32*JB]; slab index = chunk * WP + wp
+    constexpr int ROWS = (IA == 4) ? WA * 128 : 32, COLS = (JB4 == 4) ? WB * 128 : 32;
+    float *slab = partial + T.part_off + (int64_t)(chunk * WP + wp) * (ROWS * (COLS + 1));
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 8 * (r >> 2) + 4 * half + (r & 3);               // accumulator row = A row group of this wave's set
+            const int row = (IA == 4) ? 4 * (wa * 32 + m) + i : m;
+            if (JB4 == 4) {
+                const int col = 4 * (wb * 32 + (lane & 31));
+                *reinterpret_cast<f32x4 *>(slab + row * COLS + col) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+            } else {
+                slab[row * COLS + (lane & 31)] = acc[i][0][r];
+            }
+        }
+    if (wb == 0) {
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const float sum = bsum[i] + __shfl_xor(bsum[i], 32, WAVE);     // the two point parities of the row group
+            const int row = (IA == 4) ? 4 * (wa * 32 + (lane & 31)) + i : (lane & 31);
+            if (half == 0) slab[ROWS * COLS + row] = sum;
+        }
+    }
+}
+
+struct GradPtrs {
+    float *p[N_PARAMS];            // NeRF: 24 tensors; the FiLM-SIREN field uses the first 22
+};
+
+// slab reduction: blockIdx.y = task.  (A template only so that every translation unit including this header may
+// instantiate it.)
+template <int TAG>
+__global__ void dw_reduce_kernel(DwPlan plan, const float *__restrict__ partial, GradPtrs G) {
+    const DwTask T = plan.t[blockIdx.y];
+    const int rows = T.JB * 32, cols = T.KB * 32;
+    const int slab = rows * (cols + 1);
+    const int out_f_valid = T.a_valid, in_valid = T.b_valid;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < slab; idx += gridDim.x * blockDim.x) {
+        const float *src = partial + T.part_off + idx;
+        // fixed summation order (bit-reproducible); unrolled so the slab loads of a thread are all in flight at once
+        // instead of one HBM round trip per chunk
+        float s = 0.f;
+        int c = 0;
+        for (; c + 8 <= T.chunks; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(c + u) * slab];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c < T.chunks; ++c) s += src[(int64_t)c * slab];
+        if (idx < rows * cols) {
+            const int j = idx / cols, k = idx % cols;
+            if (j < out_f_valid && k < in_valid) G.p[T.param][j * T.in_f + T.out_col0 + k] = s;
+        } else if (T.bias_param >= 0) {
+            const int j = idx - rows * cols;
+            if (j < out_f_valid) G.p[T.bias_param][j] = s;
+        }
+    }
+}
+
+
+// chunk split + slab offsets of a plan whose tasks are filled in: chunks[kind] workgroups per task, sized so that the
+// grid is exactly 256 equal workgroups (one per CU)
+static inline void dw_finish_plan(DwPlan &P, const int *kind_jb, const int *kind_kb, const int *chunks_by_kind, int64_t ld) {
+    const int64_t tiles = ld / 32;
+    int wg = 0, off = 0;
+    for (int i = 0; i < P.n_tasks; ++i) {
+        DwTask &t = P.t[i];
+        t.JB = kind_jb[t.kind]; t.KB = kind_kb[t.kind];
+        int c = chunks_by_kind[t.kind];
+        if (c > tiles) c = (int)(tiles < 1 ? 1 : tiles);
+        const int wp = t.wp > 1 ? t.wp : 1;
+        t.wp = wp;
+        t.chunks = c * wp; t.wg0 = wg; t.part_off = off;
+        wg += c;
+        off += c * wp * (t.JB * 32 * (t.KB * 32 + 1));
+    }
+    P.n_wg = wg;
+}
+
+static inline size_t dw_partial_floats(const DwPlan &P) {
+    const DwTask &t = P.t[P.n_tasks - 1];
+    return (size_t)t.part_off + (size_t)t.chunks * (t.JB * 32 * (t.KB * 32 + 1));
+}
+
+}  // namespace nerfmi
