@@ -152,7 +152,7 @@ int nerfmi_siren_forward_rays(const float *packed, const float *rays, const floa
 
 /* Training path of the FiLM-SIREN field (autograd of models/nerf.py:142-151, :201-216 w.r.t. the 22 parameters; the
  * inputs carry no gradient; the conditioning rows: nerfmi_siren_backward_cond).  The *_train forwards also write `saved`
- * (nerfmi_siren_saved_floats(n_points) floats: per 32-point tile the layer inputs and one sign bit of cos per unit);
+ * (nerfmi_siren_saved_floats(n_points) floats: per 32-point tile the layer inputs (the sines) and cos(arg) of every unit);
  * nerfmi_siren_backward turns grad_out (n_points,4) = [d rgb, d sigma] into the 22 gradients (written, not
  * accumulated; bit-reproducible: fixed-order slab reduction, no float atomics).  grad_params: HOST array of 22 DEVICE
  * pointers in state_dict order; workspace: nerfmi_siren_backward_workspace_floats(n_points) floats. */

@@ -2,13 +2,13 @@
 // (SemanticNeRF.forward_with_frequencies_phase_shifts) w.r.t. the 22 parameters.
 //
 //  0. siren_forward_kernel<., false, SAVE = true> (siren_core.h): the forward that also writes, per 32-point tile, the
-//     layer inputs the dW GEMM needs (the sines themselves) and one sign bit of cos(arg) per unit.
+//     layer inputs the dW GEMM needs (the sines themselves) and cos(arg) of every unit.
 //  1. siren_backward_chain_kernel -- the dX chain.  Same register-resident scheme as the NeRF chain (mlp_bwd.hip): a
 //     wave owns 32 points, dZ_l^T lives in the accumulator layout and is the B operand of
 //     dH_{l-1}^T = W_l^T . dZ_l^T (A = the transposed packed image).  The activation derivative is
-//         d sin(fr * pre + ph) / d pre = fr * cos(arg),   |cos(arg)| = sqrt(1 - s^2),  s = the saved sine,
-//     with the sign from the forward's bitmask: nothing but the sines is re-read.  Every dZ_l goes to the workspace as
-//     a tile-major image.
+//         d sin(fr * pre + ph) / d pre = fr * cos(arg),
+//     the cosine read back from the forward's lane-private cosine image (siren_core.h SS_COS: one 16-byte load per slice).
+//     Every dZ_l goes to the workspace as a tile-major image.
 //  2. dW_l = dZ_l^T . X_l: the NeRF dW GEMM (dw_core.h) on a 12-task plan of exactly 256 workgroups.
 //  3. deterministic slab reduction (siren_dw_reduce_kernel below): bit-reproducible gradients -- and, when the launch
 //     shares ONE conditioning row, the gradients of that row (frequencies, phase_shifts: nerf.py:147-151, :201-216 are
@@ -32,24 +32,24 @@ constexpr int SW_DRGB = 9 * 256;           // 3 (+1 pad): d rgb pre-sigmoid
 constexpr int SW_DSIG = SW_DRGB + 4;       // 1 (+3 pad): d sigma
 constexpr int SW_ROWS = SW_DSIG + 4;
 
-// the 16 saved sines of block (row0 .. row0+31) that belong to this lane's accumulator registers
-__device__ __forceinline__ f32x16 load_block(const RowImage &im, int row0) {
+// the 16 saved cosines of block jb of `layer` that belong to this lane's accumulator registers: four 16-byte loads
+__device__ __forceinline__ f32x16 load_cos_block(const RowImage &im, int layer, int jb) {
     f32x16 v;
-    const float *src = im.tile + (row0 + 4 * (im.lane >> 5)) * 32 + (im.lane & 31);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[4 * q + t] = __builtin_nontemporal_load(src + (8 * q + t) * 32);   // read once: keep L2 for the weights
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 c = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(cos_slice(im, layer, jb, q)));   // read once
+        v[4 * q] = c[0]; v[4 * q + 1] = c[1]; v[4 * q + 2] = c[2]; v[4 * q + 3] = c[3];
+    }
     return v;
 }
 
-// d pre = d h * fr * cos(arg) for the four units of slice q of block jb (layer `layer`):
-// s = saved sines (this lane's 16 of the block), sign bits of the cosines in mk, fr from LDS (COND_LDS) or memory
+// d pre = d h * fr * cos(arg) for the four units of slice q of block jb (layer `layer`): cs = the forward's saved cosines
+// (this lane's 16 of the block), fr from LDS (COND_LDS) or memory.  Two packed multiplies per pair.
 // Returns dZ = fr * G (the next layer's MFMA operand); `g` receives what goes to the workspace image: G = dh * cos(arg) when
 // the launch shares one conditioning row (COND_LDS: the reduction scales the rows by fr), dZ otherwise.
 template <bool COND_LDS>
-__device__ __forceinline__ f32x4 film_grad(f32x4 dh, const f32x16 &s, const unsigned (&mk)[4], const float *fq,
-                                           const float *lfr, int layer, int jb, int q, f32x4 &g) {
+__device__ __forceinline__ f32x4 film_grad(f32x4 dh, const f32x16 &cs, const float *fq, const float *lfr, int layer, int jb,
+                                           int q, f32x4 &g) {
     f32x4 fr;
     if (COND_LDS) {
         fr = *reinterpret_cast<const f32x4 *>(lfr + 256 * layer + 32 * jb + 8 * q);
@@ -58,26 +58,9 @@ __device__ __forceinline__ f32x4 film_grad(f32x4 dh, const f32x16 &s, const unsi
 #pragma unroll
         for (int t = 0; t < 4; ++t) fr[t] = __fadd_rn(__fmul_rn(f[t], 15.0f), 30.0f);                  // nerf.py:202
     }
-    // Two values per instruction where the ISA has a packed fp32 form (v_pk_fma_f32 / v_pk_mul_f32 issue like their scalar
-    // forms, tools/ubench/pk_valu.hip): cos^2 = 1 - s^2 in one rounding (no worse than the sine's own), the products with
-    // dh and fr.  |cos| by the raw v_sqrt_f32 (1 ulp, two issue slots; sqrtf() is expanded to the correctly rounded
-    // sequence -- scale, refine, classify: ~14 instructions -- and |cos| feeds a product, not a parity check) of |cos^2|
-    // through the free |x| source modifier: a saved sine one ulp above 1 gives cos^2 = -1.2e-7, where the true |cos| is below
-    // 5e-4 either way.  The cosine's sign: bit (sh + t) of the mask word moved to bit 31 and OR-ed in (v_lshlrev + v_and_or).
-    const f32x2 one = {1.0f, 1.0f};
-    f32x2 cs[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const f32x2 sv = {s[4 * q + 2 * h], s[4 * q + 2 * h + 1]};
-        const f32x2 c2 = fma2(-sv, sv, one);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int t = 2 * h + e;
-            const float ca = __builtin_amdgcn_sqrtf(__builtin_fabsf(c2[e]));
-            const unsigned sgn = (mk[jb >> 1] << (31 - (16 * (jb & 1) + 4 * q + t))) & 0x80000000u;
-            cs[h][e] = __uint_as_float(__float_as_uint(ca) | sgn);
-        }
-        const f32x2 gg = f32x2{dh[2 * h], dh[2 * h + 1]} * cs[h];
+        const f32x2 gg = f32x2{dh[2 * h], dh[2 * h + 1]} * f32x2{cs[4 * q + 2 * h], cs[4 * q + 2 * h + 1]};
         const f32x2 dz = gg * f32x2{fr[2 * h], fr[2 * h + 1]};
         dh[2 * h] = dz[0]; dh[2 * h + 1] = dz[1];
         g[2 * h] = COND_LDS ? gg[0] : dz[0]; g[2 * h + 1] = COND_LDS ? gg[1] : dz[1];
@@ -127,12 +110,10 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
     const float dsig = go.w;
 
     f32x16 dzA[8], dzB[8];
-    unsigned mk[4];
     // d h_c = W_rgb^T d pre;  dZ_c = d h_c * fr_8 * cos(arg_c)          (nerf.py:213-214)
-    load_mask_row(S, SS_MASK + 8 * 8, mk);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        const f32x16 sv = load_block(S, SS_HC + 32 * b);
+        const f32x16 sv = load_cos_block(S, 8, b);
         f32x16 v;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -144,7 +125,7 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
             for (int t = 0; t < 4; ++t)
                 dh[t] = __builtin_fmaf(w[2][t], dpre[2], __builtin_fmaf(w[1][t], dpre[1], w[0][t] * dpre[0]));
             f32x4 g;
-            dh = film_grad<COND_LDS>(dh, sv, mk, fq, lfr, 8, b, q, g);
+            dh = film_grad<COND_LDS>(dh, sv, fq, lfr, 8, b, q, g);
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[4 * q + t] = dh[t];
             store_slice(Wk, SW_DZ + 8 * 256 + 32 * b, q, g);
@@ -155,26 +136,24 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
     const int wid = threadIdx.x >> 6;
     WeightStage ws;
     // d h_7 = W_c[:, 3:]^T dZ_c + w_sigma d sigma;  dZ_7 = d h_7 * fr_7 * cos(arg_7)      (nerf.py:212-213)
-    load_mask_row(S, SS_MASK + 8 * 7, mk);
     layer_mfma_lds<8, 0, 8, 0, true>(packed + SOFF_TCOLOR, nullptr, dzA, nullptr, dzB,
-                                     [&S](int jb) { return load_block(S, SS_H + 7 * 256 + 32 * jb); },
+                                     [&S](int jb) { return load_cos_block(S, 7, jb); },
                                      [&](int jb, int q, f32x4 c, const f32x16 &sv) {
                                          const f32x4 w = ldg4(packed + SOFF_W_SIGMA + 32 * jb + 8 * q + 4 * half);
 #pragma unroll
                                          for (int t = 0; t < 4; ++t) c[t] = __builtin_fmaf(w[t], dsig, c[t]);
                                          f32x4 g;
-                                         c = film_grad<COND_LDS>(c, sv, mk, fq, lfr, 7, jb, q, g);
+                                         c = film_grad<COND_LDS>(c, sv, fq, lfr, 7, jb, q, g);
                                          store_slice(Wk, SW_DZ + 7 * 256 + 32 * jb, q, g);
                                          return c;
                                      }, wlds, ws, wid, lane);
     // network.7 .. network.1: d h_{l-1} = W_l^T dZ_l;  dZ_{l-1} = d h_{l-1} * fr_{l-1} * cos(arg_{l-1})
     auto back = [&](int l, const f32x16 *in, f32x16 *out_dz) __attribute__((always_inline)) {
-        load_mask_row(S, SS_MASK + 8 * (l - 1), mk);
         layer_mfma_lds<8, 0, 8, 0, false>(packed + SOFF_T7 + (7 - l) * SZ_HID, nullptr, in, nullptr, out_dz,
-                                          [&S, l](int jb) { return load_block(S, SS_H + (l - 1) * 256 + 32 * jb); },
+                                          [&S, l](int jb) { return load_cos_block(S, l - 1, jb); },
                                           [&, l](int jb, int q, f32x4 c, const f32x16 &sv) {
                                               f32x4 g;
-                                              c = film_grad<COND_LDS>(c, sv, mk, fq, lfr, l - 1, jb, q, g);
+                                              c = film_grad<COND_LDS>(c, sv, fq, lfr, l - 1, jb, q, g);
                                               store_slice(Wk, SW_DZ + (l - 1) * 256 + 32 * jb, q, g);
                                               return c;
                                           }, wlds, ws, wid, lane);

@@ -39,24 +39,24 @@ constexpr int SS_D = 32;                  // 32 rows: ray direction (rows 3..31 
 constexpr int SS_H = 64;                  // 8 x 256 rows: outputs of network.0..7 (the sines)
 constexpr int SS_HC = SS_H + 8 * 256;     // 256 rows: output of color_layer_sine
 constexpr int SS_RGB = SS_HC + 256;       // 3 rows (+1 pad): sigmoid output
-// sign bits of cos(freq * pre + phase), 9 x 8 rows, same lane/register map as the NeRF ReLU masks (mlp_layout.h S_MASK):
-// the backward needs d sin = freq * cos(arg); |cos| = sqrt(|1 - s^2|) comes from the saved sine s, the sign from
-// here -- so no second 1 KB/point/layer image of arguments or cosines is written.
-constexpr int SS_MASK = SS_RGB + 4;
-constexpr int SIREN_SAVED_ROWS = SS_MASK + 9 * 8;
+// cos(freq * pre + phase) of every unit, 9 x 256 row-equivalents: the backward needs d sin = freq * cos(arg).  Rounds 1-2
+// kept one SIGN BIT per unit and rebuilt |cos| = sqrt(1 - s^2) from the saved sine in the chain kernel: ~10 vector
+// instructions per value there (a v_sqrt_f32, the bit extraction, four 4-byte loads of the sines per slice) next to fp32
+// MFMAs that do not overlap with them.  Round 3: the forward has the argument in a register and v_cos_f32 costs two issue
+// slots, so it writes the cosines themselves -- in a LANE-PRIVATE order, not as rows: slice (layer, jb, q) of a tile is the
+// 1 KiB  [64 lanes][4 units]  at  tile + (SS_COS + 256 layer) * 32 + ((4 jb + q) * 64 + lane) * 4:  ONE 16-byte store per
+// slice in the forward, ONE 16-byte load per slice in the chain kernel (same lane / register map on both sides; nothing else
+// reads it), and the chain's epilogue is two packed multiplies per pair.  Price: 1 KB / point / layer more HBM written.
+constexpr int SS_COS = SS_RGB + 4;
+constexpr int SIREN_SAVED_ROWS = SS_COS + 9 * 256;
+
+__device__ __forceinline__ float *cos_slice(const RowImage &im, int layer, int jb, int q) {
+    return im.tile + (SS_COS + 256 * layer) * 32 + ((4 * jb + q) * 64 + im.lane) * 4;
+}
 
 struct SirenParamPtrs {
     const float *p[SIREN_N_PARAMS];
 };
-
-__device__ __forceinline__ void store_mask_row(const RowImage &im, int row, unsigned (&mk)[4]) {
-    *reinterpret_cast<u32x4 *>(im.tile + row * 32 + 4 * im.lane) = u32x4{mk[0], mk[1], mk[2], mk[3]};
-    mk[0] = mk[1] = mk[2] = mk[3] = 0u;
-}
-__device__ __forceinline__ void load_mask_row(const RowImage &im, int row, unsigned (&mk)[4]) {
-    const u32x4 v = *reinterpret_cast<const u32x4 *>(im.tile + row * 32 + 4 * im.lane);
-    mk[0] = v[0]; mk[1] = v[1]; mk[2] = v[2]; mk[3] = v[3];
-}
 
 // The FiLM activation  sin(fr * pre + phase),  fr = 15 f + 30  (nerf.py:151, :202)  on gfx950 (round 3):
 //   * v_sin_f32 takes its argument in REVOLUTIONS and -- measured on MI355X, tools/ubench/hw_sin.hip,
@@ -68,12 +68,10 @@ __device__ __forceinline__ void load_mask_row(const RowImage &im, int row, unsig
 //     phase' = phase / 2pi  -- one rounding of the argument where the reference makes two (freq * x, + phase); both differ
 //     from the exact argument by ~|arg| * 6e-8.  Two values per instruction: v_pk_fma_f32 issues like v_fma_f32
 //     (tools/ubench/pk_valu.hip, profiles/r03_ubench_pk_valu.txt).
-//   * the sign of cos(arg), which the backward needs beside the saved sine: cos(2 pi t) >= 0  <=>  rint(2 t) is even, and
-//     the parity of rint(2t) is bit 0 of fma(t, 2, 1.5 * 2^23) -- one more packed fma per pair + one v_alignbit per value.
-// Forward epilogue: 2.5 issue slots per value at inference, 4 with the sign bits (rounds 1-2: 14 / 15).  Measured
+//   * training: v_cos_f32 of the same t gives the cosine the backward needs (SS_COS below), two more issue slots.
+// Forward epilogue: 2.5 issue slots per value at inference, 4.5 with the cosines (rounds 1-2: 14 / 15).  Measured
 // (same box, round 3): forward-with-save 0.725 -> 0.783 of the fp32 MFMA peak, inference 0.77 -> 0.823, step 5.50 -> 5.31 ms.
 constexpr float INV_2PI = 0.15915494309189535f;
-constexpr float RINT_MAGIC = 12582912.0f;    // 1.5 * 2^23: x + MAGIC rounds x to an integer kept in the low mantissa bits
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -95,21 +93,14 @@ __device__ __forceinline__ void stage_film(float *film, const float *__restrict_
     __syncthreads();
 }
 
-// four FiLM activations: c <- sin(2 pi (fr' c + ph')); SAVE: the sign bits of the cosines are funnel-shifted into `mkw`
-// from the top, ONE instruction per value (v_alignbit: {jbits, mk} >> 1).  After the 32 insertions of blocks 2w, 2w+1 --
-// always in the order q, t -- value (jb, q, t) sits at bit 16*(jb&1) + 4q + t, the layout the chain kernel reads.
+// four FiLM activations: c <- sin(2 pi (fr' c + ph')); SAVE: cs <- cos of the same arguments
 template <bool SAVE>
-__device__ __forceinline__ f32x4 film_sin4(f32x4 c, f32x4 fr, f32x4 ph, unsigned &mkw) {
+__device__ __forceinline__ f32x4 film_sin4(f32x4 c, f32x4 fr, f32x4 ph, f32x4 &cs) {
     const f32x2 t0 = fma2(f32x2{fr[0], fr[1]}, f32x2{c[0], c[1]}, f32x2{ph[0], ph[1]});
     const f32x2 t1 = fma2(f32x2{fr[2], fr[3]}, f32x2{c[2], c[3]}, f32x2{ph[2], ph[3]});
-    if (SAVE) {
-        const f32x2 two = {2.0f, 2.0f}, magic = {RINT_MAGIC, RINT_MAGIC};
-        const f32x2 j0 = fma2(t0, two, magic), j1 = fma2(t1, two, magic);
-        mkw = __builtin_amdgcn_alignbit(__float_as_uint(j0[0]), mkw, 1);
-        mkw = __builtin_amdgcn_alignbit(__float_as_uint(j0[1]), mkw, 1);
-        mkw = __builtin_amdgcn_alignbit(__float_as_uint(j1[0]), mkw, 1);
-        mkw = __builtin_amdgcn_alignbit(__float_as_uint(j1[1]), mkw, 1);
-    }
+    if (SAVE)
+        cs = f32x4{__builtin_amdgcn_cosf(t0[0]), __builtin_amdgcn_cosf(t0[1]), __builtin_amdgcn_cosf(t1[0]),
+                   __builtin_amdgcn_cosf(t1[1])};
     return f32x4{__builtin_amdgcn_sinf(t0[0]), __builtin_amdgcn_sinf(t0[1]), __builtin_amdgcn_sinf(t1[0]),
                  __builtin_amdgcn_sinf(t1[1])};
 }
@@ -162,9 +153,8 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
     const float *fq = freq + (COND_LDS ? 0 : (p / points_per_cond) * 2304) + 4 * half;
     const float *ph = phase + (COND_LDS ? 0 : (p / points_per_cond) * 2304) + 4 * half;
     const float *lfr = film + 4 * half;
-    unsigned mk[4] = {0u, 0u, 0u, 0u};
     auto film_epi = [&](int layer) {
-        return [fq, ph, lfr, layer, &S, &mk](int jb, int q, f32x4 c, int) {
+        return [fq, ph, lfr, layer, &S](int jb, int q, f32x4 c, int) {
             f32x4 fr, s;
             if (COND_LDS) {
                 fr = *reinterpret_cast<const f32x4 *>(lfr + 256 * layer + 32 * jb + 8 * q);
@@ -178,8 +168,12 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
                     s[t] = __fmul_rn(s[t], INV_2PI);
                 }
             }
-            c = film_sin4<SAVE>(c, fr, s, mk[jb >> 1]);                                                 // nerf.py:151
-            if (SAVE) store_slice(S, (layer < 8 ? SS_H + 256 * layer : SS_HC) + 32 * jb, q, c);
+            f32x4 cs;
+            c = film_sin4<SAVE>(c, fr, s, cs);                                                          // nerf.py:151
+            if (SAVE) {
+                store_slice(S, (layer < 8 ? SS_H + 256 * layer : SS_HC) + 32 * jb, q, c);
+                __builtin_nontemporal_store(cs, reinterpret_cast<f32x4 *>(cos_slice(S, layer, jb, q)));
+            }
             return c;
         };
     };
@@ -195,11 +189,9 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
     WeightStage ws;
     // ring phases: network.0 is 2 stages, every hidden layer 16, so the hidden and color layers start at phase 2
     layer_mfma_lds<1, 0, 8, 0, true>(packed + SOFF_L1, bias, e, nullptr, hA, no_pre, film_epi(0), wlds, ws, wid, lane);
-    if (SAVE) store_mask_row(S, SS_MASK, mk);
     auto hidden = [&](int l, const f32x16 *in, f32x16 *out_h) __attribute__((always_inline)) {
         layer_mfma_lds<8, 0, 8, 2, false>(packed + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, in, nullptr, out_h, no_pre,
                                           film_epi(l), wlds, ws, wid, lane);
-        if (SAVE) store_mask_row(S, SS_MASK + 8 * l, mk);
     };
     hidden(1, hA, hB);
     hidden(2, hB, hA);
@@ -214,7 +206,6 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
         return;
     }
     layer_mfma_lds<1, 8, 8, 2, false>(packed + SOFF_COLOR, bias + 256 * 8, de, hB, hA, no_pre, film_epi(8), wlds, ws, wid, lane);            // nerf.py:213
-    if (SAVE) store_mask_row(S, SS_MASK + 8 * 8, mk);
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
