@@ -33,3 +33,12 @@ for cfg in "siren_train:--field siren --mode train" "siren_infer:--field siren -
   python3 tools/pmc_summary.py $O/pmc_$name $O/summary/r03_pmc_$name.json > $O/summary/r03_pmc_$name.txt
 done
 echo "all done"; ls $O/summary
+# pmc_latest.json = union of the four per-step summaries (what bench.py reads for roofline.traffic)
+python3 - <<PY
+import json, glob
+u = {}
+for f in sorted(glob.glob("$O/summary/r03_pmc_*.json")):
+    u.update(json.load(open(f)))
+json.dump(u, open("$O/summary/pmc_latest.json", "w"), indent=1, sort_keys=True)
+print("pmc_latest.json:", len(u), "kernels")
+PY
