@@ -65,7 +65,8 @@ KERNELS_BF16X3 = {
     "nerf": {"train": [("nerf_forward_bf16x3_kernel<save>", "fwd", None), ("nerf_backward_chain_bf16x3_kernel", "chain", None),
                        ("nerf_dw_bf16x3_kernel", "dw", None)],
              "infer": [("nerf_forward_bf16x3_kernel", "fwd", None), ("nerf_forward_bf16x3_kernel<sigma_only>", "fwd_sigma", None)]},
-    "siren": {"train": KERNELS["siren"]["train"],      # only the inference kernel of this field has a split-bf16 form
+    "siren": {"train": [("siren_forward_bf16x3_kernel<save>", "fwd", None), ("siren_backward_chain_bf16x3_kernel", "chain", None),
+                        ("siren_dw_bf16x3_kernel", "dw", None)],
               "infer": [("siren_forward_bf16x3_kernel", "fwd", None), ("siren_forward_bf16x3_kernel<sigma_only>", "fwd_sigma", None)]},
 }
 
@@ -593,6 +594,7 @@ def main():
                 "math": "bf16x3 (exact 3-way bf16 split of both operands, 6 bf16 MFMA per product, fp32 accumulate)",
                 "nerf_train": leg("nerf", "train", nm, KERNELS_BF16X3, 2500.0 / 6.0),
                 "nerf_infer": leg("nerf", "infer", nm, KERNELS_BF16X3, 2500.0 / 6.0),
+                "siren_train": leg("siren", "train", sm, KERNELS_BF16X3, 2500.0 / 6.0),
                 "siren_infer": leg("siren", "infer", sm, KERNELS_BF16X3, 2500.0 / 6.0)}
             nerf_siren_amd.set_math("fp32")
         del om

@@ -180,6 +180,15 @@ int nerfmi_siren_backward_cond(const float *packed, const float *saved, const fl
  * (nerfmi_siren_fast_bytes() bytes) is derived from the SIREN `packed` blob by nerfmi_siren_pack_fast. */
 size_t nerfmi_siren_fast_bytes(void);
 int nerfmi_siren_pack_fast(const float *packed, void *fast, nerfmi_stream_t stream);
+/* Training on the same math: the forward that also writes `saved` (same images as nerfmi_siren_forward_rays_train), and the
+ * backward whose dX chain and 256 x 256 dW tasks run on the bf16 matrix cores (same workspace; grad_frequencies /
+ * grad_phase_shifts both NULL, or both set for a launch that shares one conditioning row). */
+int nerfmi_siren_forward_rays_train_fast(const float *packed, const void *fast, const float *rays, const float *z,
+                                         const float *frequencies, const float *phase_shifts, int n_rays, int n_per_ray,
+                                         int64_t rays_per_cond, float *out, float *saved, nerfmi_stream_t stream);
+int nerfmi_siren_backward_fast(const float *packed, const void *fast, const float *saved, const float *grad_out,
+                               const float *frequencies, int64_t n_points, int64_t points_per_cond, float *const *grad_params,
+                               float *grad_frequencies, float *grad_phase_shifts, float *workspace, nerfmi_stream_t stream);
 int nerfmi_siren_forward_rays_fast(const float *packed, const void *fast, const float *rays, const float *z,
                                    const float *frequencies, const float *phase_shifts, int n_rays, int n_per_ray,
                                    int64_t rays_per_cond, int sigma_only, float *out, nerfmi_stream_t stream);

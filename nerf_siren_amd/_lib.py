@@ -56,6 +56,8 @@ SIGNATURES = {
     "nerfmi_profile_start": (_i, []),
     "nerfmi_profile_stop": (_i, []),
     "nerfmi_profile_report": (_i64, [C.c_char_p, C.c_size_t]),
+    "nerfmi_siren_forward_rays_train_fast": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i64, _f, _f, _f]),
+    "nerfmi_siren_backward_fast": (_i, [_f, _f, _f, _f, _f, _i64, _i64, C.POINTER(C.c_void_p), _f, _f, _f, _f]),
     "nerfmi_siren_backward_cond": (_i, [_f, _f, _f, _f, _i64, C.POINTER(C.c_void_p), _f, _f, _f, _f]),
     "nerfmi_eg3d_pack_planes": (_i, [_f, _i, _i, _i, _i, _f, _f]),
     "nerfmi_eg3d_decoder_floats": (C.c_size_t, []),

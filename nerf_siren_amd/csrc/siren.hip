@@ -53,10 +53,9 @@ __global__ void siren_pack_kernel(SirenParamPtrs P, float *__restrict__ packed) 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// OPT-IN split-bf16 FiLM-SIREN forward (bf16x3_core.h).  The fp32 kernel spends a third of its time in the
-// sin(freq * (W h + b) + phase) epilogues because fp32 MFMAs do not overlap with the wave's own vector work; here a
-// layer's raw output is put through FiLM + sin by the layer that CONSUMES it, pair by pair between its XDL MFMAs,
-// which hide most of it.  Same packed parameters, same outputs, same tolerances.
+// OPT-IN split-bf16 FiLM-SIREN forward (bf16x3_core.h): the nine dense products as six bf16 MFMAs per fp32-equivalent
+// product block, the FiLM activation of each layer by the hardware sine between the layers.  Same packed parameters, same
+// outputs, same saved images (training), same tolerances.
 // ---------------------------------------------------------------------------------------------------
 static FastTable siren_fast_table() {
     FastTable T;
@@ -65,24 +64,29 @@ static FastTable siren_fast_table() {
     add(SOFF_L1, 8, 1);
     for (int l = 1; l < 8; ++l) add(SOFF_L2 + (l - 1) * SZ_HID, 8, 8);
     add(SOFF_COLOR, 8, 9);
+    // transposed images of the backward chain, in the order it walks them (colour layer, network.7 .. network.1):
+    // (output blocks of dX, contraction blocks), units behind the forward ones
+    for (int t = 0; t < 8; ++t) T.l[n++] = FastLayer{SOFF_TRANS + t * SZ_HID, 8, 8, SIREN_FAST_FWD_UNITS + t * (SZ_HID / 512)};
     T.n = n;
-    T.n_units = SOFF_BIAS / 512;
+    T.n_units = SIREN_FAST_UNITS;
     return T;
 }
-constexpr int SIREN_FAST_UNITS = SOFF_BIAS / 512;
 
-template <bool SIGMA_ONLY>
+template <bool SIGMA_ONLY, bool SAVE, bool COND_LDS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 siren_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__restrict__ fast,
                             const float *__restrict__ rays, const float *__restrict__ z, const float *__restrict__ freq,
                             const float *__restrict__ phase, int64_t n_points, int n_per_ray, int64_t points_per_cond,
-                            float *__restrict__ out) {
+                            float *__restrict__ out, float *__restrict__ saved, int64_t ld) {
+    static_assert(!(SAVE && SIGMA_ONLY), "training saves the full (rgb, sigma) pass");
     extern __shared__ __attribute__((aligned(16))) char wlds_fast[];
     const int lane = threadIdx.x & 63, half = lane >> 5, wid = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
     const int64_t praw = wave * 32 + (lane & 31);
     const bool ok = praw < n_points;
     const int64_t p = ok ? praw : n_points - 1;
+    RowImage S;                                                       // training: same images as siren_forward_kernel<SAVE>
+    S.init(saved, wave, ld / 32, SIREN_SAVED_ROWS, lane, ok, wave * 32 < n_points);
     const float *rr = rays + (p / n_per_ray) * 8;
     const float zz = z[p];
     float x[3], d[3];
@@ -99,48 +103,67 @@ siren_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__re
         e[0][r] = (c < 3) ? __fmul_rn(x[c < 3 ? c : 0], warp) : 0.f;
         de[0][r] = (c < 3) ? d[c < 3 ? c : 0] : 0.f;
     }
-    const float *fq = freq + (p / points_per_cond) * 2304 + 4 * half;
-    const float *ph = phase + (p / points_per_cond) * 2304 + 4 * half;
-    // FiLM + sin of the pair (registers 2p, 2p+1 of block kb) of layer `layer`'s raw output (nerf.py:151, :202)
-    auto film = [fq, ph](int layer, int kb, int pr, float &x0, float &x1) {
-        const int r = 2 * pr;
-        const int u = 256 * layer + 32 * kb + 8 * (r >> 2) + (r & 3);
-        const float2 f = *reinterpret_cast<const float2 *>(fq + u), s = *reinterpret_cast<const float2 *>(ph + u);
-        // The degree-9 polynomial sin_pi here, NOT the hardware sine of the fp32 kernels (siren_core.h): this hook runs between
-        // the consuming layer's XDL MFMAs, which hide ~5 plain vector instructions each but not the transcendental unit --
-        // measured (round 3, same box): v_sin_f32 in this hook 1.08 ms per fine pass, the 13-instruction polynomial 0.90 ms.
-        unsigned jb0, jb1;
-        x0 = sin_pi(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.x, 15.0f), 30.0f), x0), s.x), jb0);
-        x1 = sin_pi(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(f.y, 15.0f), 30.0f), x1), s.y), jb1);
-    };
-    auto film_hook = [&film](int layer) {
-        return [&film, layer](int kb, int pr, float &x0, float &x1) { film(layer, kb, pr, x0, x1); };
-    };
-    auto film_all = [&film](int layer, f32x16 *h) {                  // a whole layer's output at once (no consumer layer)
+    if (SAVE) {
+        store_block(S, SS_X, e[0]);
+        store_block(S, SS_D, de[0]);
+    }
+    // FiLM constants as in the fp32 kernels (siren_core.h): pre-divided by 2 pi, one row staged in LDS or this lane's row
+    __shared__ __attribute__((aligned(16))) float film[COND_LDS ? FILM_FLOATS : 4];
+    if (COND_LDS) stage_film(film, freq, phase);
+    const float *fq = freq + (COND_LDS ? 0 : (p / points_per_cond) * 2304) + 4 * half;
+    const float *ph = phase + (COND_LDS ? 0 : (p / points_per_cond) * 2304) + 4 * half;
+    const float *lfr = film + 4 * half;
+    // Round 3: the FiLM activation of a whole layer BETWEEN the layers, by the hardware sine (film_sin4: 2.5 issue slots per
+    // value, 4.5 with the cosines) -- not in consuming-layer hooks as in rounds 1-2.  The hooks existed to hide a 13-instruction
+    // polynomial sine behind the XDL MFMAs; with v_sin_f32 the whole activation of a layer is ~2.5 k cycles beside ~34 k of MFMAs,
+    // the hook version paid more than that in scheduling constraints (inference fine pass 0.90 ms hooked).  Training: sines to the
+    // saved rows, cosines to the lane-private cosine image, exactly as siren_forward_kernel<SAVE> writes them.
+    auto film_all = [&](int layer, f32x16 *h) __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
-            for (int pr = 0; pr < 8; ++pr) {
-                float x0 = h[b][2 * pr], x1 = h[b][2 * pr + 1];
-                film(layer, b, pr, x0, x1);
-                h[b][2 * pr] = x0; h[b][2 * pr + 1] = x1;
+            for (int q = 0; q < 4; ++q) {
+                f32x4 fr, s;
+                if (COND_LDS) {
+                    fr = *reinterpret_cast<const f32x4 *>(lfr + 256 * layer + 32 * b + 8 * q);
+                    s = *reinterpret_cast<const f32x4 *>(lfr + 2304 + 256 * layer + 32 * b + 8 * q);
+                } else {
+                    const f32x4 f = ldg4(fq + 256 * layer + 32 * b + 8 * q);
+                    s = ldg4(ph + 256 * layer + 32 * b + 8 * q);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        fr[t] = film_scale(f[t]);
+                        s[t] = __fmul_rn(s[t], INV_2PI);
+                    }
+                }
+                f32x4 c = {h[b][4 * q], h[b][4 * q + 1], h[b][4 * q + 2], h[b][4 * q + 3]}, cs;
+                c = film_sin4<SAVE>(c, fr, s, cs);                                                     // nerf.py:151
+                if (SAVE) {
+                    store_slice(S, (layer < 8 ? SS_H + 256 * layer : SS_HC) + 32 * b, q, c);
+                    __builtin_nontemporal_store(cs, reinterpret_cast<f32x4 *>(cos_slice(S, layer, b, q)));
+                }
+                h[b][4 * q] = c[0]; h[b][4 * q + 1] = c[1]; h[b][4 * q + 2] = c[2]; h[b][4 * q + 3] = c[3];
             }
     };
     const float *bias = packed + SOFF_BIAS + 4 * half;
     auto img = [&](int off) { return fast + fast_fwd_elems(off); };
     f32x16 hA[8], hB[8];
     FastStage fs;
-    NoHook none;
     // ring phases: network.0 is 2 stages, every hidden layer 16, so the hidden and color layers start at phase 2
     layer_bf16x3<1, 0, 8, false, true, NoHook, NoHook, 0>(img(SOFF_L1), bias, e, nullptr, hA, wlds_fast, fs, wid, lane);
-    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 0 * SZ_HID), bias + 256 * 1, nullptr, hA, hB, wlds_fast, fs, wid, lane, none, film_hook(0));
-    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 1 * SZ_HID), bias + 256 * 2, nullptr, hB, hA, wlds_fast, fs, wid, lane, none, film_hook(1));
-    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 2 * SZ_HID), bias + 256 * 3, nullptr, hA, hB, wlds_fast, fs, wid, lane, none, film_hook(2));
-    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 3 * SZ_HID), bias + 256 * 4, nullptr, hB, hA, wlds_fast, fs, wid, lane, none, film_hook(3));
-    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 4 * SZ_HID), bias + 256 * 5, nullptr, hA, hB, wlds_fast, fs, wid, lane, none, film_hook(4));
-    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 5 * SZ_HID), bias + 256 * 6, nullptr, hB, hA, wlds_fast, fs, wid, lane, none, film_hook(5));
-    layer_bf16x3<0, 8, 8, false, false, NoHook, decltype(film_hook(0)), 2>(img(SOFF_L2 + 6 * SZ_HID), bias + 256 * 7, nullptr, hA, hB, wlds_fast, fs, wid, lane, none, film_hook(6));
-    film_all(7, hB);                                                  // network.7's output feeds sigma and the colour layer
+    film_all(0, hA);
+    auto hidden = [&](int l, const f32x16 *in, f32x16 *out_h) __attribute__((always_inline)) {
+        layer_bf16x3<0, 8, 8, false, false, NoHook, NoHook, 2>(img(SOFF_L2 + (l - 1) * SZ_HID), bias + 256 * l, nullptr, in, out_h,
+                                                              wlds_fast, fs, wid, lane);
+        film_all(l, out_h);
+    };
+    hidden(1, hA, hB);
+    hidden(2, hB, hA);
+    hidden(3, hA, hB);
+    hidden(4, hB, hA);
+    hidden(5, hA, hB);
+    hidden(6, hB, hA);
+    hidden(7, hA, hB);
     const float sigma = dot_blocks<8>(hB, packed + SOFF_W_SIGMA + 4 * half) + packed[SOFF_B_SIGMA];   // nerf.py:212
     if (SIGMA_ONLY) {
         if (ok && half == 0) out[p] = sigma;
@@ -158,6 +181,11 @@ siren_forward_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__re
         float4 o;
         o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2]; o.w = sigma;
         reinterpret_cast<float4 *>(out)[p] = o;
+    }
+    if (SAVE && half == 0 && S.live) {
+        *S.at(SS_RGB + 0) = ok ? rgb[0] : 0.f;
+        *S.at(SS_RGB + 1) = ok ? rgb[1] : 0.f;
+        *S.at(SS_RGB + 2) = ok ? rgb[2] : 0.f;
     }
 }
 
@@ -234,38 +262,72 @@ int nerfmi_siren_pack_fast(const float *packed, void *fast, nerfmi_stream_t stre
     return check_launch("siren_pack_fast");
 }
 
-int nerfmi_siren_forward_rays_fast(const float *packed, const void *fast, const float *rays, const float *z,
+static int siren_forward_fast_impl(const char *who, const float *packed, const void *fast, const float *rays, const float *z,
                                    const float *frequencies, const float *phase_shifts, int n_rays, int n_per_ray,
-                                   int64_t rays_per_cond, int sigma_only, float *out, nerfmi_stream_t stream) {
+                                   int64_t rays_per_cond, int sigma_only, float *out, float *saved, nerfmi_stream_t stream) {
     NERFMI_ENTER();
-    NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && rays_per_cond >= 1, "siren_forward_rays_fast: bad sizes");
+    NERFMI_REQUIRE(n_rays >= 0 && n_per_ray >= 1 && rays_per_cond >= 1, "%s: bad sizes", who);
     const int64_t n_points = (int64_t)n_rays * n_per_ray;
     if (n_points == 0) return NERFMI_OK;
-    NERFMI_REQUIRE(packed && fast && rays && z && frequencies && phase_shifts && out, "siren_forward_rays_fast: null pointer");
+    NERFMI_REQUIRE(packed && fast && rays && z && frequencies && phase_shifts && out, "%s: null pointer", who);
+    NERFMI_REQUIRE(!(saved && sigma_only), "%s: saved activations need the full (rgb, sigma) pass", who);
     static PerDeviceOnce attr_set;
     int attr_dev;
     if (attr_set.needed(attr_dev)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(siren_forward_bf16x3_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(siren_forward_bf16x3_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess) {
+        bool okk = true;
+#define NERFMI_RAISE(K) okk = okk && hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) == hipSuccess
+        NERFMI_RAISE((siren_forward_bf16x3_kernel<false, false, true>));
+        NERFMI_RAISE((siren_forward_bf16x3_kernel<false, false, false>));
+        NERFMI_RAISE((siren_forward_bf16x3_kernel<true, false, true>));
+        NERFMI_RAISE((siren_forward_bf16x3_kernel<true, false, false>));
+        NERFMI_RAISE((siren_forward_bf16x3_kernel<false, true, true>));
+        NERFMI_RAISE((siren_forward_bf16x3_kernel<false, true, false>));
+#undef NERFMI_RAISE
+        if (!okk) {
             (void)hipGetLastError();
-            set_error("siren_forward_rays_fast: cannot raise the dynamic LDS limit");
+            set_error("%s: cannot raise the dynamic LDS limit", who);
             return NERFMI_E_LAUNCH;
         }
         attr_set.mark(attr_dev);
     }
     const int64_t waves = (n_points + 31) / 32;
+    const int64_t ld = siren_pad_points(n_points);
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    KernelSpan span(sigma_only ? "siren_forward_bf16x3_kernel<sigma_only>" : "siren_forward_bf16x3_kernel", n_points, st);
-    if (sigma_only)
-        hipLaunchKernelGGL((siren_forward_bf16x3_kernel<true>), grid, block, FLDS_BYTES, st, packed, (const __bf16 *)fast,
-                           rays, z, frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out);
-    else
-        hipLaunchKernelGGL((siren_forward_bf16x3_kernel<false>), grid, block, FLDS_BYTES, st, packed, (const __bf16 *)fast,
-                           rays, z, frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out);
-    return check_launch("siren_forward_rays_fast");
+    const bool one_cond = rays_per_cond >= n_rays;
+    KernelSpan span(sigma_only ? "siren_forward_bf16x3_kernel<sigma_only>"
+                               : (saved ? "siren_forward_bf16x3_kernel<save>" : "siren_forward_bf16x3_kernel"), n_points, st);
+#define NERFMI_LAUNCH_FAST(SO, SV, SP)                                                                                      \
+    do {                                                                                                                    \
+        if (one_cond)                                                                                                       \
+            hipLaunchKernelGGL((siren_forward_bf16x3_kernel<SO, SV, true>), grid, block, FLDS_BYTES, st, packed,              \
+                               (const __bf16 *)fast, rays, z, frequencies, phase_shifts, n_points, n_per_ray,                \
+                               rays_per_cond * n_per_ray, out, SP, ld);                                                      \
+        else                                                                                                                \
+            hipLaunchKernelGGL((siren_forward_bf16x3_kernel<SO, SV, false>), grid, block, FLDS_BYTES, st, packed,             \
+                               (const __bf16 *)fast, rays, z, frequencies, phase_shifts, n_points, n_per_ray,                \
+                               rays_per_cond * n_per_ray, out, SP, ld);                                                      \
+    } while (0)
+    if (sigma_only) NERFMI_LAUNCH_FAST(true, false, nullptr);
+    else if (saved) NERFMI_LAUNCH_FAST(false, true, saved);
+    else NERFMI_LAUNCH_FAST(false, false, nullptr);
+#undef NERFMI_LAUNCH_FAST
+    return check_launch(who);
+}
+
+int nerfmi_siren_forward_rays_fast(const float *packed, const void *fast, const float *rays, const float *z,
+                                   const float *frequencies, const float *phase_shifts, int n_rays, int n_per_ray,
+                                   int64_t rays_per_cond, int sigma_only, float *out, nerfmi_stream_t stream) {
+    return siren_forward_fast_impl("siren_forward_rays_fast", packed, fast, rays, z, frequencies, phase_shifts, n_rays, n_per_ray,
+                                   rays_per_cond, sigma_only, out, nullptr, stream);
+}
+
+int nerfmi_siren_forward_rays_train_fast(const float *packed, const void *fast, const float *rays, const float *z,
+                                         const float *frequencies, const float *phase_shifts, int n_rays, int n_per_ray,
+                                         int64_t rays_per_cond, float *out, float *saved, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(saved || (int64_t)n_rays * n_per_ray == 0, "siren_forward_rays_train_fast: null pointer");
+    return siren_forward_fast_impl("siren_forward_rays_train_fast", packed, fast, rays, z, frequencies, phase_shifts, n_rays,
+                                   n_per_ray, rays_per_cond, 0, out, saved, stream);
 }
 
 }  // extern "C"

@@ -21,7 +21,7 @@
 //     second pass over the activations.
 #include <stdlib.h>
 
-#include "dw_core.h"
+#include "dw_bf16x3.h"
 #include "siren_core.h"
 
 namespace nerfmi {
@@ -168,6 +168,111 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
 }
 
 // ---------------------------------------------------------------------------
+// 1b. the dX chain on the bf16 matrix cores (opt-in split-bf16 math, bf16x3_core.h): same images in, same images out.
+//     The eight 256 x 256 products run as six bf16 MFMAs per fp32-equivalent product block; the FiLM derivative of a
+//     layer's raw output (two packed multiplies per pair with the saved cosines), the G / dZ stores and the next layer's
+//     operand are finished BETWEEN the layers (not in consuming-layer hooks as in the NeRF chain: the hooks would have to
+//     prefetch 16 cosines per block inside a kernel that already uses 500 registers).
+// ---------------------------------------------------------------------------
+template <bool COND_LDS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+siren_backward_chain_bf16x3_kernel(const float *__restrict__ packed, const __bf16 *__restrict__ fast,
+                                   const float *__restrict__ saved, const float *__restrict__ grad_out,
+                                   const float *__restrict__ freq, int64_t n_points, int64_t points_per_cond, int64_t ld,
+                                   float *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char wlds_fast[];
+    const int lane = threadIdx.x & 63, half = lane >> 5, wid = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t p0 = wave * 32;
+    const bool live = p0 < n_points;
+    const int64_t praw = p0 + (lane & 31);
+    const bool ok = praw < n_points;
+    const int64_t p = ok ? praw : n_points - 1;
+    RowImage S, Wk;
+    S.init(const_cast<float *>(saved), wave, ld / 32, SIREN_SAVED_ROWS, lane, ok, live);
+    Wk.init(work, wave, ld / 32, SW_ROWS, lane, ok, live);
+    __shared__ __attribute__((aligned(16))) float film[COND_LDS ? 2304 : 4];
+    if (COND_LDS) {
+        for (int i = threadIdx.x; i < 2304; i += blockDim.x) film[i] = __fadd_rn(__fmul_rn(freq[i], 15.0f), 30.0f);
+        __syncthreads();
+    }
+    const float *fq = freq + (COND_LDS ? 0 : (p / points_per_cond) * 2304) + 4 * half;
+    const float *lfr = film + 4 * half;
+
+    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) go = reinterpret_cast<const float4 *>(grad_out)[praw];
+    float dpre[3];
+    {
+        const float g3[3] = {go.x, go.y, go.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float rgb = *S.at(SS_RGB + c);
+            dpre[c] = g3[c] * rgb * (1.0f - rgb);
+            if (half == 0) *Wk.at(SW_DRGB + c) = dpre[c];
+        }
+        if (half == 0) *Wk.at(SW_DSIG) = go.w;
+    }
+    const float dsig = go.w;
+
+    f32x16 dzA[8], dzB[8];
+    // d h_c = W_rgb^T d pre;  dZ_c = d h_c * fr_8 * cos(arg_c)          (nerf.py:213-214)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const f32x16 sv = load_cos_block(S, 8, b);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 w[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w[c] = ldg4(packed + SOFF_W_RGB + 256 * c + 32 * b + 8 * q + 4 * half);
+            f32x4 dh, g;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                dh[t] = __builtin_fmaf(w[2][t], dpre[2], __builtin_fmaf(w[1][t], dpre[1], w[0][t] * dpre[0]));
+            dh = film_grad<COND_LDS>(dh, sv, fq, lfr, 8, b, q, g);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dzA[b][4 * q + t] = dh[t];
+            store_slice(Wk, SW_DZ + 8 * 256 + 32 * b, q, g);
+        }
+    }
+    // raw d h_layer (accumulator layout) -> dZ_layer in place; G (one-row launches) or dZ to the workspace image
+    auto finish = [&](int layer, f32x16 *dh) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const f32x16 sv = load_cos_block(S, layer, b);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 c = {dh[b][4 * q], dh[b][4 * q + 1], dh[b][4 * q + 2], dh[b][4 * q + 3]}, g;
+                c = film_grad<COND_LDS>(c, sv, fq, lfr, layer, b, q, g);
+                store_slice(Wk, SW_DZ + layer * 256 + 32 * b, q, g);
+                dh[b][4 * q] = c[0]; dh[b][4 * q + 1] = c[1]; dh[b][4 * q + 2] = c[2]; dh[b][4 * q + 3] = c[3];
+            }
+        }
+    };
+    FastStage fs;
+    NoHook none;
+    auto timg = [&](int t) { return fast + (int64_t)(SIREN_FAST_FWD_UNITS + t * (SZ_HID / 512)) * 1536; };
+    // d h_7 = W_c[:, 3:]^T dZ_c + w_sigma d sigma   (nerf.py:212-213)
+    layer_bf16x3<8, 0, 8, false, true>(timg(0), packed + SOFF_W_SIGMA + 4 * half, dzA, nullptr, dzB, wlds_fast, fs, wid, lane, none,
+                                       none, dsig);
+    finish(7, dzB);
+    // network.7 .. network.1: d h_{l-1} = W_l^T dZ_l
+    layer_bf16x3<8, 0, 8, false, false>(timg(1), nullptr, dzB, nullptr, dzA, wlds_fast, fs, wid, lane);
+    finish(6, dzA);
+    layer_bf16x3<8, 0, 8, false, false>(timg(2), nullptr, dzA, nullptr, dzB, wlds_fast, fs, wid, lane);
+    finish(5, dzB);
+    layer_bf16x3<8, 0, 8, false, false>(timg(3), nullptr, dzB, nullptr, dzA, wlds_fast, fs, wid, lane);
+    finish(4, dzA);
+    layer_bf16x3<8, 0, 8, false, false>(timg(4), nullptr, dzA, nullptr, dzB, wlds_fast, fs, wid, lane);
+    finish(3, dzB);
+    layer_bf16x3<8, 0, 8, false, false>(timg(5), nullptr, dzB, nullptr, dzA, wlds_fast, fs, wid, lane);
+    finish(2, dzA);
+    layer_bf16x3<8, 0, 8, false, false>(timg(6), nullptr, dzA, nullptr, dzB, wlds_fast, fs, wid, lane);
+    finish(1, dzB);
+    layer_bf16x3<8, 0, 8, false, false>(timg(7), nullptr, dzB, nullptr, dzA, wlds_fast, fs, wid, lane);
+    finish(0, dzA);
+}
+
+// ---------------------------------------------------------------------------
 // 2. dW: same GEMM as the NeRF backward on the SIREN images
 // ---------------------------------------------------------------------------
 #ifdef NERFMI_TIMING
@@ -194,6 +299,23 @@ siren_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__rest
 #ifdef NERFMI_TIMING
     if (threadIdx.x == 0) nerfmi_dbg_siren_dw[blockIdx.x] = __builtin_readcyclecounter() - t_start;
 #endif
+}
+
+// the 256 x 256 tasks on the bf16 matrix cores (dw_bf16x3.h); the narrow tasks stay on the fp32 path
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+siren_dw_bf16x3_kernel(DwPlan plan, const float *__restrict__ work, const float *__restrict__ saved, int64_t ld,
+                       float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int ti = 0;
+    for (int i = 1; i < plan.n_tasks; ++i)
+        if ((int)blockIdx.x >= plan.t[i].wg0) ti = i;
+    const DwTask T = plan.t[ti];
+    const int chunk = blockIdx.x - T.wg0;
+    switch (T.kind) {
+        case 0: dw_task_bf16x3<8, 8, 4, 4, 2, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, reinterpret_cast<char *>(lds)); break;
+        case 1: dw_task<2, 1, 4, 1, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;
+        default: dw_task<1, 2, 1, 4, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -268,7 +390,7 @@ siren_dw_reduce_kernel(DwPlan plan, const float *__restrict__ partial, GradPtrs 
 static const int SKIND_JB[3] = {8, 8, 1};
 static const int SKIND_KB[3] = {8, 1, 8};
 
-static DwPlan siren_plan(int64_t ld) {
+static DwPlan siren_plan(int64_t ld, bool fast = false) {
     DwPlan P;
     int n = 0;
     auto add = [&](int kind, int a_row0, int a_valid, int b_row0, int b_valid, int param, int col0, int in_f, int bias) {
@@ -288,7 +410,10 @@ static DwPlan siren_plan(int64_t ld) {
     // The two K = 3 tasks (network.0: X = xyz; colour layer: dir columns) use the narrowest B tile there is, 32 columns:
     // as 64-column tasks they kept 20 workgroups busy multiplying zero padding.
     static const int chunks_default[3] = {29, 6, 6};
-    const int *chunks = chunks_default;
+    // split-bf16 variant: the 256 x 256 tasks run ~2x faster per tile, so the fp32 narrow tasks get the larger share of CUs:
+    // 8 x 24 + 2 x 16 + 2 x 16 = 256
+    static const int chunks_fast[3] = {24, 16, 16};
+    const int *chunks = fast ? chunks_fast : chunks_default;
 #ifdef NERFMI_TIMING
     // experiment builds only (tools/exp_siren_dw_timing.py): "c0,c1,c2", validated -- the product never reads the environment
     int chunks_env[3];
@@ -357,8 +482,8 @@ int nerfmi_siren_forward_points_train(const float *packed, const float *points, 
     return check_launch("siren_forward_points_train");
 }
 
-static int siren_backward_impl(const char *who, const float *packed, const float *saved, const float *grad_out,
-                               const float *frequencies, int64_t n_points, int64_t points_per_cond,
+static int siren_backward_impl(const char *who, const float *packed, const void *fast, const float *saved,
+                               const float *grad_out, const float *frequencies, int64_t n_points, int64_t points_per_cond,
                                float *const *grad_params, float *grad_frequencies, float *grad_phase_shifts,
                                float *workspace, nerfmi_stream_t stream) {
     NERFMI_ENTER();
@@ -382,29 +507,49 @@ static int siren_backward_impl(const char *who, const float *packed, const float
     float *work = workspace;
     float *partial = workspace + (size_t)SW_ROWS * (ld + 32);
     const int64_t waves = (n_points + 31) / 32;
-    const DwPlan P = siren_plan(ld);
+    const DwPlan P = siren_plan(ld, fast != nullptr);       // (the split-bf16 plan's slabs fit the fp32 plan's workspace)
     const size_t lds = sizeof(float) * 2 * 512 * LROW;  // two 73 728-B tile buffers (> the 64 KiB default dynamic-LDS limit)
+    static_assert(2 * DWF_KSTEP_BYTES <= sizeof(float) * 2 * 512 * LROW, "the split-bf16 k-step buffers fit in the same allocation");
     static PerDeviceOnce attr_set;
     int attr_dev;
     if (attr_set.needed(attr_dev)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(siren_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
+                                (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(siren_dw_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(siren_backward_chain_bf16x3_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(siren_backward_chain_bf16x3_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess) {
             (void)hipGetLastError();
             set_error("%s: cannot raise the dynamic LDS limit", who);
             return NERFMI_E_LAUNCH;
         }
         attr_set.mark(attr_dev);
     }
-    {
-        KernelSpan span("siren_backward_chain_kernel", n_points, st);
-        if (one_cond)   // the workspace images hold G = dZ / fr; the reduction scales the rows (header of this file)
-            hipLaunchKernelGGL(siren_backward_chain_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed,
-                               saved, grad_out, frequencies, n_points, points_per_cond, ld, work);
-        else
-            hipLaunchKernelGGL(siren_backward_chain_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, packed,
-                               saved, grad_out, frequencies, n_points, points_per_cond, ld, work);
-    }
-    {
+    const dim3 cgrid((unsigned)((waves + 3) / 4));
+    if (fast) {
+        {
+            KernelSpan span("siren_backward_chain_bf16x3_kernel", n_points, st);
+            if (one_cond)
+                hipLaunchKernelGGL(siren_backward_chain_bf16x3_kernel<true>, cgrid, dim3(256), FLDS_BYTES, st, packed,
+                                   (const __bf16 *)fast, saved, grad_out, frequencies, n_points, points_per_cond, ld, work);
+            else
+                hipLaunchKernelGGL(siren_backward_chain_bf16x3_kernel<false>, cgrid, dim3(256), FLDS_BYTES, st, packed,
+                                   (const __bf16 *)fast, saved, grad_out, frequencies, n_points, points_per_cond, ld, work);
+        }
+        KernelSpan span("siren_dw_bf16x3_kernel", n_points, st);
+        hipLaunchKernelGGL(siren_dw_bf16x3_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
+    } else {
+        {
+            KernelSpan span("siren_backward_chain_kernel", n_points, st);
+            if (one_cond)   // the workspace images hold G = dZ / fr; the reduction scales the rows (header of this file)
+                hipLaunchKernelGGL(siren_backward_chain_kernel<true>, cgrid, dim3(256), 0, st, packed, saved, grad_out, frequencies,
+                                   n_points, points_per_cond, ld, work);
+            else
+                hipLaunchKernelGGL(siren_backward_chain_kernel<false>, cgrid, dim3(256), 0, st, packed, saved, grad_out,
+                                   frequencies, n_points, points_per_cond, ld, work);
+        }
         KernelSpan span("siren_dw_kernel", n_points, st);
         hipLaunchKernelGGL(siren_dw_kernel, dim3(P.n_wg), dim3(256), lds, st, P, work, saved, ld, partial);
     }
@@ -419,16 +564,27 @@ static int siren_backward_impl(const char *who, const float *packed, const float
 int nerfmi_siren_backward(const float *packed, const float *saved, const float *grad_out, const float *frequencies,
                           int64_t n_points, int64_t points_per_cond, float *const *grad_params, float *workspace,
                           nerfmi_stream_t stream) {
-    return siren_backward_impl("siren_backward", packed, saved, grad_out, frequencies, n_points, points_per_cond, grad_params,
-                               nullptr, nullptr, workspace, stream);
+    return siren_backward_impl("siren_backward", packed, nullptr, saved, grad_out, frequencies, n_points, points_per_cond,
+                               grad_params, nullptr, nullptr, workspace, stream);
 }
 
 int nerfmi_siren_backward_cond(const float *packed, const float *saved, const float *grad_out, const float *frequencies,
                                int64_t n_points, float *const *grad_params, float *grad_frequencies,
                                float *grad_phase_shifts, float *workspace, nerfmi_stream_t stream) {
     NERFMI_REQUIRE(grad_frequencies && grad_phase_shifts, "siren_backward_cond: null conditioning-gradient pointer");
-    return siren_backward_impl("siren_backward_cond", packed, saved, grad_out, frequencies, n_points, n_points, grad_params,
-                               grad_frequencies, grad_phase_shifts, workspace, stream);
+    return siren_backward_impl("siren_backward_cond", packed, nullptr, saved, grad_out, frequencies, n_points, n_points,
+                               grad_params, grad_frequencies, grad_phase_shifts, workspace, stream);
+}
+
+// The same backward with the dX chain and the 256 x 256 tasks of the dW GEMM on the bf16 matrix cores (opt-in split-bf16 math;
+// `fast` = nerfmi_siren_pack_fast's image).  grad_frequencies / grad_phase_shifts: both NULL, or both set for a launch that
+// shares one conditioning row (points_per_cond >= n_points).
+int nerfmi_siren_backward_fast(const float *packed, const void *fast, const float *saved, const float *grad_out,
+                               const float *frequencies, int64_t n_points, int64_t points_per_cond, float *const *grad_params,
+                               float *grad_frequencies, float *grad_phase_shifts, float *workspace, nerfmi_stream_t stream) {
+    NERFMI_REQUIRE(fast, "siren_backward_fast: null pointer");
+    return siren_backward_impl("siren_backward_fast", packed, fast, saved, grad_out, frequencies, n_points, points_per_cond,
+                               grad_params, grad_frequencies, grad_phase_shifts, workspace, stream);
 }
 
 }  // extern "C"

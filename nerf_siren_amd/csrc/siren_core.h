@@ -30,6 +30,10 @@ constexpr int SOFF_TCOLOR = SOFF_TRANS;             // 8 kbo x 8 jb
 constexpr int SOFF_T7 = SOFF_TCOLOR + SZ_HID;       // network.l at SOFF_T7 + (7 - l) * SZ_HID, l = 7..1
 // readable tail: the weight streams prefetch two stages past their last layer
 constexpr int SIREN_PACKED_FLOATS = SOFF_T7 + 7 * SZ_HID + STREAM_TAIL;
+// split-bf16 image (bf16x3_core.h): a unit = 512 floats of `packed` = 3 x 1 KiB; the forward layers' units, then the eight
+// transposed images of the backward chain in the order it walks them
+constexpr int SIREN_FAST_FWD_UNITS = SOFF_BIAS / 512;
+constexpr int SIREN_FAST_UNITS = SIREN_FAST_FWD_UNITS + 8 * (SZ_HID / 512);
 constexpr int SIREN_N_PARAMS = 22;  // network.{0..7}.layer.{weight,bias}, final_layer.*, color_layer_sine.layer.*, color_layer_linear.0.*
 static_assert(SOFF_TRANS - SOFF_BIAS + 8 * SZ_HID >= 2 * GS * 256, "the forward stream's prefetch stays inside the image");
 

@@ -415,8 +415,9 @@ def _siren_cond(freq, phase, n_groups, per_cond):
     return freq, phase
 
 
-def siren_forward_rays_train(packed, rays, z, freq, phase, rays_per_cond):
-    """Training forward of the FiLM-SIREN field behind the ray sampler -> (out (n*p,4), saved)."""
+def siren_forward_rays_train(packed, rays, z, freq, phase, rays_per_cond, fast=None):
+    """Training forward of the FiLM-SIREN field behind the ray sampler -> (out (n*p,4), saved).
+    fast: the split-bf16 image (siren_pack_fast) to run it on the bf16 matrix cores (opt-in math)."""
     rays = _req(rays, "rays", (None, 8))
     z = _req(z, "z", (rays.shape[0], None))
     n, p = z.shape
@@ -425,9 +426,14 @@ def siren_forward_rays_train(packed, rays, z, freq, phase, rays_per_cond):
     out = torch.empty((n * p, 4), device=rays.device, dtype=torch.float32)
     saved = torch.empty(_lib.lib().nerfmi_siren_saved_floats(n * p), device=rays.device, dtype=torch.float32)
     with _Span("siren_forward_rays_train", p):
-        check(_lib.lib().nerfmi_siren_forward_rays_train(ptr(packed), ptr(rays), ptr(z), ptr(freq), ptr(phase), n, p,
-                                                         int(rays_per_cond), ptr(out), ptr(saved), _stream(rays)),
-              "siren_forward_rays_train")
+        if fast is not None:
+            check(_lib.lib().nerfmi_siren_forward_rays_train_fast(ptr(packed), ptr(fast), ptr(rays), ptr(z), ptr(freq), ptr(phase),
+                                                                  n, p, int(rays_per_cond), ptr(out), ptr(saved), _stream(rays)),
+                  "siren_forward_rays_train_fast")
+        else:
+            check(_lib.lib().nerfmi_siren_forward_rays_train(ptr(packed), ptr(rays), ptr(z), ptr(freq), ptr(phase), n, p,
+                                                             int(rays_per_cond), ptr(out), ptr(saved), _stream(rays)),
+                  "siren_forward_rays_train")
     return out, saved
 
 
@@ -445,10 +451,11 @@ def siren_forward_points_train(packed, points, dirs, freq, phase, points_per_con
     return out, saved
 
 
-def siren_backward(packed, saved, grad_out, freq, points_per_cond, grads=None, cond_grads=False):
+def siren_backward(packed, saved, grad_out, freq, points_per_cond, grads=None, cond_grads=False, fast=None):
     """-> list of 22 gradient tensors (SIREN_PARAM_ORDER), written not accumulated.
     cond_grads=True (the launch must share ONE conditioning row): -> (grads, d frequencies (1, 2304), d phase_shifts (1, 2304))
-    through nerfmi_siren_backward_cond."""
+    through nerfmi_siren_backward_cond.  fast: the split-bf16 image (siren_pack_fast): dX chain and the 256 x 256 dW tasks on
+    the bf16 matrix cores (opt-in math)."""
     grad_out = _req(grad_out, "grad_out", (None, 4))
     n = grad_out.shape[0]
     freq = _req(freq, "frequencies", (None, 2304))
@@ -459,9 +466,16 @@ def siren_backward(packed, saved, grad_out, freq, points_per_cond, grads=None, c
     if grads is None:
         grads = siren_flat_views(torch.empty(SIREN_PARAM_NUMEL, device=grad_out.device, dtype=torch.float32))
     ws = torch.empty(_lib.lib().nerfmi_siren_backward_workspace_floats(n), device=grad_out.device, dtype=torch.float32)
+    if cond_grads and points_per_cond < n:
+        raise ValueError("siren_backward(cond_grads=True) needs a launch that shares one conditioning row")
+    if fast is not None:
+        d_cond = torch.empty((2, 2304), device=grad_out.device, dtype=torch.float32) if cond_grads else None
+        check(_lib.lib().nerfmi_siren_backward_fast(ptr(packed), ptr(fast), ptr(saved), ptr(grad_out), ptr(freq), n,
+                                                    int(points_per_cond), _ptr_array(grads),
+                                                    ptr(d_cond[0]) if cond_grads else None, ptr(d_cond[1]) if cond_grads else None,
+                                                    ptr(ws), _stream(grad_out)), "siren_backward_fast")
+        return (grads, d_cond[0:1], d_cond[1:2]) if cond_grads else grads
     if cond_grads:
-        if points_per_cond < n:
-            raise ValueError("siren_backward(cond_grads=True) needs a launch that shares one conditioning row")
         d_cond = torch.empty((2, 2304), device=grad_out.device, dtype=torch.float32)
         check(_lib.lib().nerfmi_siren_backward_cond(ptr(packed), ptr(saved), ptr(grad_out), ptr(freq), n, _ptr_array(grads),
                                                     ptr(d_cond[0]), ptr(d_cond[1]), ptr(ws), _stream(grad_out)),

@@ -23,7 +23,7 @@ _MATH = "fp32"
 def set_math(mode: str):
     """Arithmetic of the MLP matrix products: 'fp32' (default, exact fp32 MFMA) or 'bf16x3' (opt-in: exact three-way
     bf16 splits on the bf16 matrix cores, fp32-level accuracy): all forward passes (inference and the training
-    forward that saves activations) and the backward dX chain; the dW GEMM stays on the fp32 MFMA."""
+    forward that saves activations), the backward dX chain and the 256 x 256 tasks of the dW GEMM, for both fields."""
     global _MATH
     if mode not in ("fp32", "bf16x3"):
         raise ValueError("math mode must be 'fp32' or 'bf16x3'")
@@ -98,8 +98,9 @@ class FieldRender(torch.autograd.Function):
         ctx.n_field_params = len(model.param_list())      # SirenField may append its trainable conditioning rows behind them
         if siren:
             packed = model.model.packed()
-            field, saved = ops.siren_forward_rays_train(packed, rays, z, model.frequencies, model.phase_shifts, rays.shape[0])
-            ctx.fast = None
+            ctx.fast = model.model.packed_fast() if _MATH == "bf16x3" else None
+            field, saved = ops.siren_forward_rays_train(packed, rays, z, model.frequencies, model.phase_shifts, rays.shape[0],
+                                                        fast=ctx.fast)
         else:
             packed = model.packed()
             if _MATH == "bf16x3":
@@ -136,10 +137,10 @@ class FieldRender(torch.autograd.Function):
         cond = ()
         if siren and n_cond:
             grads, d_f, d_p = ops.siren_backward(packed, saved, grad_field, ctx.model.frequencies, z.numel(), grads=out,
-                                                 cond_grads=True)
+                                                 cond_grads=True, fast=ctx.fast)
             cond = (d_f.view_as(ctx.model.frequencies), d_p.view_as(ctx.model.phase_shifts))
         elif siren:
-            grads = ops.siren_backward(packed, saved, grad_field, ctx.model.frequencies, z.numel(), grads=out)
+            grads = ops.siren_backward(packed, saved, grad_field, ctx.model.frequencies, z.numel(), grads=out, fast=ctx.fast)
         else:
             grads = ops.nerf_backward_rays(packed, rays, z, saved, grad_field, grads=out, fast=ctx.fast)
         _grad_ready(ctx.model, out)

@@ -69,7 +69,7 @@ def test_argument_validation_without_gpu(libpath):
     assert l.nerfmi_siren_forward_points_train(None, None, None, None, None, 5, 0, None, None, None) == -1   # per_cond >= 1
     assert l.nerfmi_siren_backward(None, None, None, None, 0, 1, None, None, None) == -1                      # n_points >= 1
     assert l.nerfmi_siren_backward(None, None, None, None, 64, 64, None, None, None) == -1
-    assert l.nerfmi_siren_saved_floats(64) == 2444 * (64 + 32)                     # csrc/siren_core.h SIREN_SAVED_ROWS + dump tile
+    assert l.nerfmi_siren_saved_floats(64) == 4676 * (64 + 32)                     # csrc/siren_core.h SIREN_SAVED_ROWS + dump tile
     assert l.nerfmi_siren_backward_workspace_floats(64) > 2312 * (64 + 32)
     assert l.nerfmi_siren_packed_floats() == 1076736                               # forward + small + transposed images + stream tail (siren_core.h)
     assert l.nerfmi_nerf_forward_embedded_train(None, None, 8, None, None, None) == -1

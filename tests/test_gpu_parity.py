@@ -764,11 +764,23 @@ def test_siren_conditioning_gradients_vs_reference_autograd(golden, dev, siren):
         o_.siren_backward(pk, saved, T(gg["G"].reshape(-1, 4), dev), T(g["freq"], dev), 41, cond_grads=True)
 
 
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("n_rays", [37, 200])
-def test_siren_render_rays_training(dev, n_rays):
+def test_siren_render_rays_training(dev, n_rays, math):
     """render_rays([SirenField, SirenField]) in training mode (perturb, noise, white_back) against the oracle pipeline:
     outputs, and the gradients of both fields' 22 parameters (compositor backward -> SIREN backward).  The fine
-    pass is conditioned on the oracle's merged depths (rng['z_fine'])."""
+    pass is conditioned on the oracle's merged depths (rng['z_fine']).  math = bf16x3 (round 3): forward-with-save, dX chain
+    and the 256 x 256 dW tasks of this field on the split-bf16 path, same tolerances."""
+    import nerf_siren_amd
+    from nerf_siren_amd import Embedding, SemanticNeRF, SirenField, render_rays
+    nerf_siren_amd.set_math(math)
+    try:
+        _siren_training_body(dev, n_rays)
+    finally:
+        nerf_siren_amd.set_math("fp32")
+
+
+def _siren_training_body(dev, n_rays):
     from nerf_siren_amd import Embedding, SemanticNeRF, SirenField, render_rays
     ps = [synth.siren_params(3), synth.siren_params(4)]
     conds = [(synth.hash_normal((1, 2304), 311 + i), synth.hash_normal((1, 2304), 321 + i)) for i in range(2)]
@@ -1128,7 +1140,7 @@ def test_psnr_parity(golden, dev, impl):
     assert np.abs(np.array(psnr) - ref).max() < 0.1, (psnr, ref)
 
 
-@pytest.mark.parametrize("impl", ["torch", "fused"])
+@pytest.mark.parametrize("impl", ["torch", "fused", "fused+bf16x3"])
 def test_psnr_parity_siren(golden, dev, impl):
     """The same protocol with the FiLM-SIREN field as the student (g15s: the reference's SemanticNeRF trained by the
     reference's render_rays + torch autograd on CPU, tools/make_psnr_golden.py --siren): 240 Adam steps through the HIP
