@@ -58,6 +58,26 @@ def test_argument_validation_without_gpu(libpath):
     assert l.nerfmi_generate_rays(None, 1, 4, 4, -1.0, None, 16, 0, 2.0, 6.0, None, None) == -1
     assert l.nerfmi_ray_directions(0, 4, 5.0, None, None) == -1
     assert l.nerfmi_get_rays(None, None, 0, None, None, None) == 0
+    # round 3: the one-call render, the conditioning-gradient backward, the split-bf16 SIREN training entries, the in-kernel
+    # EG3D draws and the profiler validate the same way
+    a24 = [None] * 24
+    assert l.nerfmi_render_rays_fused(2, *a24[:5], 4, 64, 64, 0, 0.0, 0.0, 1, 0, 1, 2, *a24[:8]) == -1 and b"field_kind" in l.nerfmi_last_error()
+    assert l.nerfmi_render_rays_fused(0, *a24[:5], 4, 64, 64, 0, 0.0, 0.0, 1, 0, 1, 2, *a24[:8]) == -1 and b"null" in l.nerfmi_last_error()
+    assert l.nerfmi_render_rays_fused(0, *a24[:5], 0, 64, 64, 0, 0.0, 0.0, 1, 0, 1, 2, *a24[:8]) == 0          # empty batch
+    assert l.nerfmi_render_rays_workspace_floats(1024, 64, 64, 0) == 1024 * (64 + 64 + 256 + 128 + 512)
+    assert l.nerfmi_render_rays_workspace_floats(1024, 64, 0, 1) == 1024 * (64 + 64 + 64)
+    import ctypes as C
+    gp = (C.c_void_p * 22)()
+    assert l.nerfmi_siren_backward_cond(None, None, None, None, 64, gp, None, None, None, None) == -1
+    assert b"conditioning-gradient" in l.nerfmi_last_error()
+    assert l.nerfmi_siren_backward_fast(None, None, None, None, None, 64, 64, gp, None, None, None, None) == -1
+    assert l.nerfmi_siren_forward_rays_train_fast(None, None, None, None, None, None, 4, 64, 4, None, None, None) == -1
+    assert l.nerfmi_siren_forward_rays_train_fast(None, None, None, None, None, None, 0, 64, 1, None, None, None) == 0
+    assert l.nerfmi_eg3d_sample_stratified_philox(None, None, 0.0, 1.0, 1, 2, 8, 48, 0, None, None) == -1
+    assert l.nerfmi_eg3d_sample_importance_philox(None, None, 1, 2, 8, 48, 48, None, None) == -1
+    assert l.nerfmi_eg3d_sample_stratified(None, None, 0.0, 1.0, None, 8, 48, 0, None, None) == -1
+    # the profiler is inert without launches: start / report (empty) / stop
+    assert l.nerfmi_profile_start() == 0 and l.nerfmi_profile_report(None, 0) == 0 and l.nerfmi_profile_stop() == 0
     assert l.nerfmi_nerf_forward_rays_fast(None, None, None, None, 4, 8, 0, None, None, None) == -1
     assert l.nerfmi_nerf_backward_rays_fast(None, None, 4, 8, None, None, None, None, None) == -1
     assert l.nerfmi_siren_forward_rays_fast(None, None, None, None, None, None, 0, 8, 1, 0, None, None) == 0
