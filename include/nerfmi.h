@@ -180,7 +180,9 @@ int nerfmi_siren_backward_cond(const float *packed, const float *saved, const fl
  * (nerfmi_siren_fast_bytes() bytes) is derived from the SIREN `packed` blob by nerfmi_siren_pack_fast. */
 size_t nerfmi_siren_fast_bytes(void);
 int nerfmi_siren_pack_fast(const float *packed, void *fast, nerfmi_stream_t stream);
-/* Training on the same math: the forward that also writes `saved` (same images as nerfmi_siren_forward_rays_train), and the
+/* Training on the same math: the forward that also writes `saved` (same size and row map as nerfmi_siren_forward_rays_train's,
+ * but a different element order inside a 32-point tile: a `saved` image is OPAQUE and must be handed to the backward of the
+ * math that wrote it -- _train -> nerfmi_siren_backward[_cond], _train_fast -> nerfmi_siren_backward_fast), and the
  * backward whose dX chain and 256 x 256 dW tasks run on the bf16 matrix cores (same workspace; grad_frequencies /
  * grad_phase_shifts both NULL, or both set for a launch that shares one conditioning row). */
 int nerfmi_siren_forward_rays_train_fast(const float *packed, const void *fast, const float *rays, const float *z,

@@ -17,7 +17,8 @@ struct DwTask {
     int out_col0;   // first column of the weight this task covers
     int in_f;       // row stride of the weight tensor
     int bias_param; // bias tensor index or -1
-    int chunks;     // split of the point range
+    int chunks;     // split of the point range = number of partial slabs
+    int wp;         // dw_task4g: slabs per workgroup (the tile's points split over two wave pairs); 1 otherwise
     int wg0;        // first workgroup of this task
     int part_off;   // float offset of this task's slabs in the partial buffer
     int JB, KB;     // block counts (rows/cols of the slab = 32*JB x 32*KB)
@@ -159,6 +160,170 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dW on the "x4" images of the FiLM-SIREN training path (round 3), staged by LDS-DMA.
+//
+// x4 layout: element (row r, point p) of a 32-point tile lives at  tile + ((r >> 2) * 32 + p) * 4 + (r & 3):  the four rows of a
+// ROW GROUP are interleaved per point.  In the MLP kernels a lane owns four consecutive units of one point (registers 4q..4q+3
+// of an accumulator block), so a slice of a saved / dZ image is ONE 16-byte store (a wave: 1 KiB contiguous) where the
+// [row][32 points] layout needs four 4-byte stores -- a vector-memory instruction costs the same issue slot and TA time
+// whatever its width (tools/ubench/pk_valu.hip).
+//
+// The GEMM needs no transposing staging: the rows of an MFMA operand may be ANY 32 rows.  A lane reads one 16-byte LDS word
+// = (row group g = its lane & 31, point 2s + (lane >> 5)) = the four units 4g..4g+3 of one point and feeds unit i of it to MFMA
+// i: operand A_i is "unit i of 32 consecutive row groups" (rows 4g + i), B_j likewise, and the 4 x 4 products A_i (x) B_j
+// fill a 128 x 128 tile of dW whose rows / columns are merely interleaved -- undone for free when the slab is written.  Per
+// 32-point tile a wave issues 2 LDS reads per 16 MFMAs (the [row][point] kernel above: 10 per 16).
+//
+// Staging: `global_load_lds_dwordx4` (no staging registers, no ds_write): with 256 accumulator registers a register-staged
+// version of this loop made hipcc spill 113-177 VGPRs into the MFMA loop (tools/experiments/README.md).  An LDS-DMA
+// instruction writes 64 lanes x 16 B = 1 KiB CONTIGUOUSLY; which 16 bytes of global memory a lane fetches is free.  A PIECE
+// = two row groups (1 KiB of the image) is stored with its two row groups interleaved per point -- LDS slot 2 p + (g & 1)
+// holds (row group g, point p): DMA lane L fetches image word (L & 1) * 32 + (L >> 1) -- and pieces are 1056 bytes apart.
+// The fragment address of a lane is then AFFINE in the k-step (base + 64 s: an immediate offset), and the 16 lanes of a
+// ds_read_b128 pass (consecutive row groups, one point) start 16 B apart inside a piece and 1056 B = 8 banks + 16 rows
+// apart across pieces: 16 different 4-bank groups.  All of the next tile's pieces are issued in the first half of the
+// current tile's steps, so that the vmcnt(0) the barrier at the tile's end needs finds them landed.
+//   kind 0  256 x 256 : IA = 4, JB4 = 4, waves 2 (A sets) x 2 (B sets)
+//   kind 1  256 x 3   : the three input columns sit in unit 0 of row groups 0..2 (rows 0, 4, 8): IA = 4, JB4 = 1; waves
+//                       2 (A sets) x 2 (halves of the tile's points, written as two slabs: the reduction sums slabs anyway)
+//   kind 2  3 x 256   : the head's dZ rows sit in unit 0 of row groups 0..2: IA = 1, JB4 = 4; waves 2 (B sets) x 2 (point halves)
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) void gbl_void_t;
+
+template <int IA, int JB4, int WA, int WB, int WP, int AROWS, int BROWS>
+__device__ __forceinline__ void dw_task4g(const DwTask &T, int chunk, const float *__restrict__ work,
+                                          const float *__restrict__ saved, int64_t ld, float *__restrict__ partial,
+                                          float *lds) {
+    static_assert(WA * WB * WP == 4, "four waves per workgroup");
+    constexpr int PIECE = 1056;                           // LDS bytes between pieces (1 KiB + 32: see above)
+    constexpr int NA_P = (IA == 4) ? WA * 16 : 2;         // pieces staged per tile
+    constexpr int NB_P = (JB4 == 4) ? WB * 16 : 2;
+    constexpr int A_AL = NA_P < 16 ? 16 : NA_P;           // a wave's 32 lanes read 32 row groups: keep the reads inside LDS
+    constexpr int B_AL = NB_P < 16 ? 16 : NB_P;
+    constexpr int BUF_BYTES = (A_AL + B_AL) * PIECE;
+    constexpr bool A_FIRST = NA_P >= NB_P;                // piece order of a tile: the wide operand first
+    constexpr int NP = NA_P + NB_P, NJ = (NP + 3) / 4;    // pieces per tile, per wave
+    constexpr int STEPS = 16 / WP;                        // k-steps (point pairs) of a tile that this wave multiplies
+    constexpr int ISSUE_STEPS = STEPS / 2;                // the next tile's pieces go out in the first half of the steps
+    constexpr int PER_STEP = (NJ + ISSUE_STEPS - 1) / ISSUE_STEPS;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: piece addresses stay in SGPRs)
+    const int wa = wid % WA, wb = (wid / WA) % WB, wp = wid / (WA * WB);
+    const int wg_chunks = T.chunks / WP;                  // workgroups of this task (T.chunks counts slabs)
+    const int64_t tiles = ld / 32;
+    const int64_t t_lo = tiles * chunk / wg_chunks, t_hi = tiles * (chunk + 1) / wg_chunks;
+    const char *abase = reinterpret_cast<const char *>(work + (int64_t)T.a_row0 * 32);
+    const char *bbase = reinterpret_cast<const char *>(saved + (int64_t)T.b_row0 * 32);
+    char *lbase = reinterpret_cast<char *>(lds);
+    const unsigned poff = (unsigned)((lane & 1) * 512 + (lane >> 1) * 16);   // this lane's word of a piece
+    // piece 4 j + wave of a tile (rounds j < NF / 4: the wide operand, 4 | its piece count; then the narrow operand's pieces)
+    // from the tile's operand bases `sa`, `sb` into `buf`
+    constexpr int NF = A_FIRST ? NA_P : NB_P;
+    static_assert(NF % 4 == 0, "the wide operand's pieces fill whole rounds");
+    auto issue = [&](int j, const char *sa, const char *sb, char *buf) __attribute__((always_inline)) {
+        const bool first = j < NF / 4;                    // compile-time after unrolling
+        const int p = first ? 4 * j + wid : 4 * (j - NF / 4) + wid;
+        if ((NP - NF) % 4 != 0 && !first && p >= NP - NF) return;   // (wave-uniform; only the narrow operand has a ragged round)
+        const bool is_a = first == A_FIRST;
+        const char *src = (is_a ? sa : sb) + p * 1024;
+        char *dst = buf + (is_a ? 0 : A_AL * PIECE) + p * PIECE;
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + poff), (lds_void_t *)dst, 16, 0, 0);
+    };
+
+    f32x16 acc[IA][JB4];
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+#pragma unroll
+        for (int j = 0; j < JB4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x2 bsum2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // bias sums: sum over points of the A rows (units 0..3 of the lane's row group)
+
+    char *buf0 = lbase;
+    if (t_lo < t_hi) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) issue(j, abase + t_lo * (int64_t)(AROWS * 128), bbase + t_lo * (int64_t)(BROWS * 128), buf0);
+    }
+    __syncthreads();                                      // (hipcc drains the LDS-DMAs in flight with vmcnt(0) here)
+    // fragment bases: (row group g, point 2 s + half) at piece (g >> 1), slot 2 (2 s + half) + (g & 1)
+    const int rga = ((IA == 4) ? wa * 32 : 0) + (lane & 31), rgb = ((JB4 == 4) ? wb * 32 : 0) + (lane & 31);
+    const unsigned a_off = (unsigned)((rga >> 1) * PIECE + (rga & 1) * 16 + half * 32 + STEPS * wp * 64);
+    const unsigned b_off = (unsigned)(A_AL * PIECE + (rgb >> 1) * PIECE + (rgb & 1) * 16 + half * 32 + STEPS * wp * 64);
+    // ONE tile per loop trip, the two buffers swapped by offset arithmetic: with all 256 accumulator registers in use, a loop
+    // body of two unrolled tiles (the second one conditional) makes hipcc spill an accumulator block around the join
+    int cur = 0;                                          // byte offset of the buffer being consumed
+    for (int64_t t = t_lo; t < t_hi; ++t) {
+        const int64_t t1 = (t + 1 < t_hi) ? t + 1 : t_hi - 1;   // past the end: restage the last tile (branch-free)
+        const char *sa = abase + t1 * (int64_t)(AROWS * 128), *sb = bbase + t1 * (int64_t)(BROWS * 128);
+        const char *ca = lbase + cur + a_off, *cb = lbase + cur + b_off;
+        char *nxt = lbase + (BUF_BYTES - cur);
+        // fragments are read ONE step ahead into a second register set, in the MIDDLE of the step's MFMAs (fenced, so that the
+        // reads stay there): a read issued right in front of its first MFMA exposes its whole latency, and so does one issued
+        // right behind the last MFMA of the step before (hipcc waits with lgkmcnt(0), which covers the newest read too)
+        f32x4 a = *reinterpret_cast<const f32x4 *>(ca), b = *reinterpret_cast<const f32x4 *>(cb);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            // (volatile asm: written in C, the compiler sinks the sixteen steps' adds to the end of the tile and keeps all
+            // sixteen A fragments alive until then)
+            if (IA == 4) {
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(bsum2[0]) : "v"(f32x2{a[0], a[1]}));
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(bsum2[1]) : "v"(f32x2{a[2], a[3]}));
+            } else {
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum2[0][0]) : "v"(a[0]));
+            }
+#pragma unroll
+            for (int m = 0; m < IA * JB4 / 2; ++m)
+                acc[m / JB4][m % JB4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m / JB4], b[m % JB4], acc[m / JB4][m % JB4], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 an = a, bn = b;
+            if (s + 1 < STEPS) {
+                an = *reinterpret_cast<const f32x4 *>(ca + 64 * (s + 1));
+                bn = *reinterpret_cast<const f32x4 *>(cb + 64 * (s + 1));
+            }
+            if (s < ISSUE_STEPS) {
+#pragma unroll
+                for (int k = 0; k < PER_STEP; ++k)
+                    if (s * PER_STEP + k < NJ) issue(s * PER_STEP + k, sa, sb, nxt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = IA * JB4 / 2; m < IA * JB4; ++m)
+                acc[m / JB4][m % JB4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m / JB4], b[m % JB4], acc[m / JB4][m % JB4], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a = an; b = bn;
+        }
+        __syncthreads();
+        cur = BUF_BYTES - cur;
+    }
+    // slab [32*JB rows][32*KB cols] then the bias slab [32*JB]; slab index = chunk * WP + wp
+    constexpr int ROWS = (IA == 4) ? WA * 128 : 32, COLS = (JB4 == 4) ? WB * 128 : 32;
+    float *slab = partial + T.part_off + (int64_t)(chunk * WP + wp) * (ROWS * (COLS + 1));
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 8 * (r >> 2) + 4 * half + (r & 3);               // accumulator row = A row group of this wave's set
+            const int row = (IA == 4) ? 4 * (wa * 32 + m) + i : m;
+            if (JB4 == 4) {
+                const int col = 4 * (wb * 32 + (lane & 31));
+                *reinterpret_cast<f32x4 *>(slab + row * COLS + col) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+            } else {
+                slab[row * COLS + (lane & 31)] = acc[i][0][r];
+            }
+        }
+    if (wb == 0) {
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const float mine = bsum2[i >> 1][i & 1];
+            const float sum = mine + __shfl_xor(mine, 32, WAVE);           // the two point parities of the row group
+            const int row = (IA == 4) ? 4 * (wa * 32 + (lane & 31)) + i : (lane & 31);
+            if (half == 0) slab[ROWS * COLS + row] = sum;
+        }
+    }
+}
+
 struct GradPtrs {
     float *p[N_PARAMS];            // NeRF: 24 tensors; the FiLM-SIREN field uses the first 22
 };
@@ -206,9 +371,11 @@ static inline void dw_finish_plan(DwPlan &P, const int *kind_jb, const int *kind
         t.JB = kind_jb[t.kind]; t.KB = kind_kb[t.kind];
         int c = chunks_by_kind[t.kind];
         if (c > tiles) c = (int)(tiles < 1 ? 1 : tiles);
-        t.chunks = c; t.wg0 = wg; t.part_off = off;
+        const int wp = t.wp > 1 ? t.wp : 1;
+        t.wp = wp;
+        t.chunks = c * wp; t.wg0 = wg; t.part_off = off;
         wg += c;
-        off += c * (t.JB * 32 * (t.KB * 32 + 1));
+        off += c * wp * (t.JB * 32 * (t.KB * 32 + 1));
     }
     P.n_wg = wg;
 }

@@ -305,7 +305,7 @@ static DwPlan make_plan(int64_t ld, bool fast = false) {
     auto add = [&](int kind, int a_row0, int a_valid, int b_row0, int b_valid, int param, int col0, int in_f, int bias) {
         DwTask &t = P.t[n++];
         t.kind = kind; t.a_row0 = a_row0; t.a_valid = a_valid; t.b_row0 = b_row0; t.b_valid = b_valid;
-        t.param = param; t.out_col0 = col0; t.in_f = in_f; t.bias_param = bias;
+        t.param = param; t.out_col0 = col0; t.in_f = in_f; t.bias_param = bias; t.wp = 1;
         t.JB = KIND_JB[kind]; t.KB = KIND_KB[kind];
     };
     add(1, W_DZ, 256, S_EMB, 63, 0, 0, 63, 1);                                       // xyz_encoding_1

@@ -9,6 +9,7 @@ namespace nerfmi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 
 __device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
@@ -266,6 +267,16 @@ __device__ __forceinline__ void store_slice(const RowImage &im, int row0, int q,
 #else
     for (int t = 0; t < 4; ++t) __builtin_nontemporal_store(v[t], dst + 32 * t);
 #endif
+}
+// The "x4" images of the fp32 FiLM-SIREN training path (round 3; dw_core.h dw_task4g): element (row r, point p) of a tile at
+// tile + ((r >> 2) * 32 + p) * 4 + (r & 3).  A lane's slice -- units row0 + 8q + 4*half + {0..3} of its point -- is ONE
+// 16-byte word, a wave's slice two contiguous 512-byte runs: one global_store_dwordx4 per slice.
+__device__ __forceinline__ float *at4(const RowImage &im, int r) {
+    return im.tile + ((r >> 2) * 32 + (im.lane & 31)) * 4 + (r & 3);
+}
+__device__ __forceinline__ void store_slice4(const RowImage &im, int row0, int q, f32x4 v) {
+    float *dst = im.tile + (((row0 + 8 * q) >> 2) + (im.lane >> 5)) * 128 + (im.lane & 31) * 4;
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));       // streamed once, read back by a later kernel
 }
 __device__ __forceinline__ void store_block(const RowImage &im, int row0, const f32x16 &v) {
 #pragma unroll

@@ -28,9 +28,12 @@ namespace nerfmi {
 
 // workspace row map (tile-major images written by the chain kernel)
 constexpr int SW_DZ = 0;                   // 9 x 256: dZ of network.0..7, then color_layer_sine (G = dZ / fr in one-row launches)
-constexpr int SW_DRGB = 9 * 256;           // 3 (+1 pad): d rgb pre-sigmoid
-constexpr int SW_DSIG = SW_DRGB + 4;       // 1 (+3 pad): d sigma
-constexpr int SW_ROWS = SW_DSIG + 4;
+// head rows: [row][32 points] order in the split-bf16 chain (rows SW_DRGB + c, SW_DSIG); x4 order in the fp32 chain, where they
+// sit in unit 0 of their own row groups (rows SW_DRGB + 4c and SW_DSIG4) for dw_task4g's narrow-A form
+constexpr int SW_DRGB = 9 * 256;           // d rgb pre-sigmoid
+constexpr int SW_DSIG = SW_DRGB + 4;       // d sigma ([row][point] order)
+constexpr int SW_DSIG4 = SW_DRGB + 16;     // d sigma (x4 order: the narrow-A task reads row groups 0..3 from its first row)
+constexpr int SW_ROWS = SW_DRGB + 32;
 
 // the 16 saved cosines of block jb of `layer` that belong to this lane's accumulator registers: four 16-byte loads
 __device__ __forceinline__ f32x16 load_cos_block(const RowImage &im, int layer, int jb) {
@@ -103,9 +106,9 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
         for (int c = 0; c < 3; ++c) {
             const float rgb = *S.at(SS_RGB + c);
             dpre[c] = g3[c] * rgb * (1.0f - rgb);
-            if (half == 0) *Wk.at(SW_DRGB + c) = dpre[c];
+            if (half == 0) *at4(Wk, SW_DRGB + 4 * c) = dpre[c];
         }
-        if (half == 0) *Wk.at(SW_DSIG) = go.w;
+        if (half == 0) *at4(Wk, SW_DSIG4) = go.w;
     }
     const float dsig = go.w;
 
@@ -128,7 +131,7 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
             dh = film_grad<COND_LDS>(dh, sv, fq, lfr, 8, b, q, g);
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[4 * q + t] = dh[t];
-            store_slice(Wk, SW_DZ + 8 * 256 + 32 * b, q, g);
+            store_slice4(Wk, SW_DZ + 8 * 256 + 32 * b, q, g);
         }
         dzA[b] = v;
     }
@@ -144,7 +147,7 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
                                          for (int t = 0; t < 4; ++t) c[t] = __builtin_fmaf(w[t], dsig, c[t]);
                                          f32x4 g;
                                          c = film_grad<COND_LDS>(c, sv, fq, lfr, 7, jb, q, g);
-                                         store_slice(Wk, SW_DZ + 7 * 256 + 32 * jb, q, g);
+                                         store_slice4(Wk, SW_DZ + 7 * 256 + 32 * jb, q, g);
                                          return c;
                                      }, wlds, ws, wid, lane);
     // network.7 .. network.1: d h_{l-1} = W_l^T dZ_l;  dZ_{l-1} = d h_{l-1} * fr_{l-1} * cos(arg_{l-1})
@@ -154,7 +157,7 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
                                           [&, l](int jb, int q, f32x4 c, const f32x16 &sv) {
                                               f32x4 g;
                                               c = film_grad<COND_LDS>(c, sv, fq, lfr, l - 1, jb, q, g);
-                                              store_slice(Wk, SW_DZ + (l - 1) * 256 + 32 * jb, q, g);
+                                              store_slice4(Wk, SW_DZ + (l - 1) * 256 + 32 * jb, q, g);
                                               return c;
                                           }, wlds, ws, wid, lane);
     };
@@ -292,9 +295,10 @@ siren_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__rest
     const DwTask T = plan.t[ti];
     const int chunk = blockIdx.x - T.wg0;
     switch (T.kind) {
-        case 0: dw_task<2, 8, 4, 1, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 256
-        case 1: dw_task<2, 1, 4, 1, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 32 (3 real columns)
-        default: dw_task<1, 2, 1, 4, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;  // 32 x 256
+        // dw_core.h dw_task4g<IA, JB4, WA, WB, WP>
+        case 0: dw_task4g<4, 4, 2, 2, 1, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 256
+        case 1: dw_task4g<4, 1, 2, 1, 2, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 3 (x, y, z / direction)
+        default: dw_task4g<1, 4, 1, 2, 2, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;  // 3 x 256 (heads)
     }
 #ifdef NERFMI_TIMING
     if (threadIdx.x == 0) nerfmi_dbg_siren_dw[blockIdx.x] = __builtin_readcyclecounter() - t_start;
@@ -397,6 +401,8 @@ static DwPlan siren_plan(int64_t ld, bool fast = false) {
         DwTask &t = P.t[n++];
         t.kind = kind; t.a_row0 = a_row0; t.a_valid = a_valid; t.b_row0 = b_row0; t.b_valid = b_valid;
         t.param = param; t.out_col0 = col0; t.in_f = in_f; t.bias_param = bias;
+        // fp32 path (dw_task4g): the narrow tasks split a tile's points over two wave pairs = two slabs per workgroup
+        t.wp = (!fast && kind != 0) ? 2 : 1;
     };
     // B rows past b_valid are whatever follows in the tile (the GEMM's extra columns are dropped by the reduction)
     add(1, SW_DZ, 256, SS_X, 3, 0, 0, 3, 1);                                                    // network.0: X = warped xyz
@@ -404,7 +410,7 @@ static DwPlan siren_plan(int64_t ld, bool fast = false) {
     add(1, SW_DZ + 256 * 8, 256, SS_D, 3, 18, 0, 259, -1);                                      // colour layer, dir columns 0..2
     add(0, SW_DZ + 256 * 8, 256, SS_H + 256 * 7, 256, 18, 3, 259, 19);                          // colour layer, hidden columns
     add(2, SW_DRGB, 3, SS_HC, 256, 20, 0, 256, 21);                                             // color_layer_linear.0
-    add(2, SW_DSIG, 1, SS_H + 256 * 7, 256, 16, 0, 256, 17);                                    // final_layer
+    add(2, fast ? SW_DSIG : SW_DSIG4, 1, SS_H + 256 * 7, 256, 16, 0, 256, 17);                  // final_layer
     P.n_tasks = n;
     // 8 x 29 + 2 x 6 + 2 x 6 = 256 workgroups, one per CU (shares from per-task workgroup stamps, tools/exp_siren_dw_timing.py).
     // The two K = 3 tasks (network.0: X = xyz; colour layer: dir columns) use the narrowest B tile there is, 32 columns:
@@ -446,7 +452,8 @@ size_t nerfmi_siren_saved_floats(int64_t n_points) {
 
 size_t nerfmi_siren_backward_workspace_floats(int64_t n_points) {
     const int64_t ld = siren_pad_points(n_points < 1 ? 1 : n_points);
-    return (size_t)SW_ROWS * (size_t)(ld + 32) + dw_partial_floats(siren_plan(ld));
+    const size_t p32 = dw_partial_floats(siren_plan(ld)), pfast = dw_partial_floats(siren_plan(ld, true));
+    return (size_t)SW_ROWS * (size_t)(ld + 32) + (p32 > pfast ? p32 : pfast);
 }
 
 int nerfmi_siren_forward_rays_train(const float *packed, const float *rays, const float *z, const float *frequencies,
@@ -508,7 +515,8 @@ static int siren_backward_impl(const char *who, const float *packed, const void 
     float *partial = workspace + (size_t)SW_ROWS * (ld + 32);
     const int64_t waves = (n_points + 31) / 32;
     const DwPlan P = siren_plan(ld, fast != nullptr);       // (the split-bf16 plan's slabs fit the fp32 plan's workspace)
-    const size_t lds = sizeof(float) * 2 * 512 * LROW;  // two 73 728-B tile buffers (> the 64 KiB default dynamic-LDS limit)
+    // split-bf16 / [row][point] tasks: two 73 728-B tile buffers; dw_task4g: two 65 536-B ones (> the 64 KiB default limit)
+    const size_t lds = sizeof(float) * 2 * 512 * LROW;
     static_assert(2 * DWF_KSTEP_BYTES <= sizeof(float) * 2 * 512 * LROW, "the split-bf16 k-step buffers fit in the same allocation");
     static PerDeviceOnce attr_set;
     int attr_dev;

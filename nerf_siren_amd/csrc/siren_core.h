@@ -37,9 +37,15 @@ constexpr int SIREN_FAST_UNITS = SIREN_FAST_FWD_UNITS + 8 * (SZ_HID / 512);
 constexpr int SIREN_N_PARAMS = 22;  // network.{0..7}.layer.{weight,bias}, final_layer.*, color_layer_sine.layer.*, color_layer_linear.0.*
 static_assert(SOFF_TRANS - SOFF_BIAS + 8 * SZ_HID >= 2 * GS * 256, "the forward stream's prefetch stays inside the image");
 
-// Activations kept for training: tile-major [tile of 32 points][row][32] images (mlp_core.h RowImage).
-constexpr int SS_X = 0;                   // 32 rows: box-warped xyz (rows 3..31 = 0)            -> X of network.0
-constexpr int SS_D = 32;                  // 32 rows: ray direction (rows 3..31 = 0)             -> X of the colour layer, dir part
+// Activations kept for training: tile-major images, same row map in two element orders:
+//   fp32 path (siren_forward_kernel<save>, siren_backward_chain_kernel, siren_dw_kernel): the "x4" order (mlp_core.h at4 /
+//     store_slice4: the four rows of a row group interleaved per point; dw_core.h dw_task4g); x, y, z / the direction sit in
+//     rows 0, 4, 8 of their block (unit 0 of row groups 0..2);
+//   split-bf16 path (siren_forward_bf16x3_kernel<save>, ..._chain_bf16x3, siren_dw_bf16x3_kernel): [row][32 points], x, y, z in
+//     rows 0..2 (rows 3..31 = 0).
+// An image is read back by the backward of the SAME math (include/nerfmi.h: nerfmi_siren_forward_*_train[_fast]).
+constexpr int SS_X = 0;                   // 32 rows: box-warped xyz                            -> X of network.0
+constexpr int SS_D = 32;                  // 32 rows: ray direction                             -> X of the colour layer, dir part
 constexpr int SS_H = 64;                  // 8 x 256 rows: outputs of network.0..7 (the sines)
 constexpr int SS_HC = SS_H + 8 * 256;     // 256 rows: output of color_layer_sine
 constexpr int SS_RGB = SS_HC + 256;       // 3 rows (+1 pad): sigmoid output
@@ -77,7 +83,6 @@ struct SirenParamPtrs {
 // (same box, round 3): forward-with-save 0.725 -> 0.783 of the fp32 MFMA peak, inference 0.77 -> 0.823, step 5.50 -> 5.31 ms.
 constexpr float INV_2PI = 0.15915494309189535f;
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // fr' = (15 f + 30) / 2pi with the reference's two roundings of fr (nerf.py:202) and one for the division
@@ -147,9 +152,13 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
         e[0][r] = (c < 3) ? __fmul_rn(x[c < 3 ? c : 0], warp) : 0.f;
         de[0][r] = (c < 3) ? d[c < 3 ? c : 0] : 0.f;
     }
-    if (SAVE) {
-        store_block(S, SS_X, e[0]);
-        store_block(S, SS_D, de[0]);
+    if (SAVE && half == 0) {
+        // the two K = 3 operands of the dW GEMM: component c in unit 0 of row group c, where dw_task4g's narrow-B form reads them
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            *at4(S, SS_X + 4 * c) = e[0][c];
+            *at4(S, SS_D + 4 * c) = de[0][c];
+        }
     }
     // conditioning: one row for the launch staged in LDS (COND_LDS), else this lane's row (n_cond, 9*256) from memory
     __shared__ __attribute__((aligned(16))) float film[COND_LDS ? FILM_FLOATS : 4];
@@ -175,7 +184,7 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
             f32x4 cs;
             c = film_sin4<SAVE>(c, fr, s, cs);                                                          // nerf.py:151
             if (SAVE) {
-                store_slice(S, (layer < 8 ? SS_H + 256 * layer : SS_HC) + 32 * jb, q, c);
+                store_slice4(S, (layer < 8 ? SS_H + 256 * layer : SS_HC) + 32 * jb, q, c);
                 __builtin_nontemporal_store(cs, reinterpret_cast<f32x4 *>(cos_slice(S, layer, jb, q)));
             }
             return c;

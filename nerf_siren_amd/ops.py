@@ -434,6 +434,7 @@ def siren_forward_rays_train(packed, rays, z, freq, phase, rays_per_cond, fast=N
             check(_lib.lib().nerfmi_siren_forward_rays_train(ptr(packed), ptr(rays), ptr(z), ptr(freq), ptr(phase), n, p,
                                                              int(rays_per_cond), ptr(out), ptr(saved), _stream(rays)),
                   "siren_forward_rays_train")
+    saved._nerfmi_math = "f32" if fast is None else "bf16x3"   # the two paths keep their images in different element orders
     return out, saved
 
 
@@ -448,6 +449,7 @@ def siren_forward_points_train(packed, points, dirs, freq, phase, points_per_con
     check(_lib.lib().nerfmi_siren_forward_points_train(ptr(packed), ptr(points), ptr(dirs), ptr(freq), ptr(phase), n,
                                                        int(points_per_cond), ptr(out), ptr(saved), _stream(points)),
           "siren_forward_points_train")
+    saved._nerfmi_math = "f32"
     return out, saved
 
 
@@ -468,6 +470,9 @@ def siren_backward(packed, saved, grad_out, freq, points_per_cond, grads=None, c
     ws = torch.empty(_lib.lib().nerfmi_siren_backward_workspace_floats(n), device=grad_out.device, dtype=torch.float32)
     if cond_grads and points_per_cond < n:
         raise ValueError("siren_backward(cond_grads=True) needs a launch that shares one conditioning row")
+    if getattr(saved, "_nerfmi_math", None) not in (None, "f32" if fast is None else "bf16x3"):
+        raise ValueError("siren_backward: the saved image was written by the %s forward; its backward must use the same math "
+                         "(the fp32 and split-bf16 paths order the image differently)" % saved._nerfmi_math)
     if fast is not None:
         d_cond = torch.empty((2, 2304), device=grad_out.device, dtype=torch.float32) if cond_grads else None
         check(_lib.lib().nerfmi_siren_backward_fast(ptr(packed), ptr(fast), ptr(saved), ptr(grad_out), ptr(freq), n,
