@@ -110,35 +110,39 @@ constexpr int NSLOT = 4;
 constexpr int WLDS_FLOATS = NSLOT * GS * 256;   // 64 KiB
 constexpr int QS = GS / 4;                 // fragments per wave per stage
 
-struct WeightStage {
-    f32x4 st[QS];                          // this wave's quarter of the stage in flight
+template <int GS_>
+struct WeightStageT {
+    f32x4 st[GS_ / 4];                     // this wave's quarter of the stage in flight
 };
+using WeightStage = WeightStageT<GS>;
 
 template <int KB0, int KB1, int JB>
 constexpr int layer_stages() { return JB * (KB0 + KB1) * 4 / GS; }
 
-template <int KB0, int KB1, int JB, int PH, bool FIRST, class Pre, class Epi>
+// GS_: fragments per stage of THIS kernel's ring (the FiLM-SIREN kernels run longer stages: siren_core.h SIREN_GS)
+template <int KB0, int KB1, int JB, int PH, bool FIRST, int GS_ = GS, class Pre, class Epi>
 __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, const float *__restrict__ bias,
                                                const f32x16 *in0, const f32x16 *in1, f32x16 *out, Pre pre, Epi epi,
-                                               float *wlds, WeightStage &ws, int wid, int lane) {
+                                               float *wlds, WeightStageT<GS_> &ws, int wid, int lane) {
+    constexpr int QS_ = GS_ / 4;
     constexpr int KBT = KB0 + KB1;
     constexpr int G = JB * KBT * 4;
-    static_assert(G % GS == 0, "a layer is a whole number of stages");
-    constexpr int NST = G / GS;
-    const float *gsrc = wbase + (QS * wid) * 256 + lane * 4;        // this wave's quarter of every stage
-    float *ldst = wlds + (QS * wid) * 256 + lane * 4;
+    static_assert(G % GS_ == 0, "a layer is a whole number of stages");
+    constexpr int NST = G / GS_;
+    const float *gsrc = wbase + (QS_ * wid) * 256 + lane * 4;        // this wave's quarter of every stage
+    float *ldst = wlds + (QS_ * wid) * 256 + lane * 4;
     const float *lsrc = wlds + lane * 4;
     auto gload = [&](int stage) {                                   // stage >= NST: the next layer's image
 #pragma unroll
-        for (int i = 0; i < QS; ++i) ws.st[i] = ldg4(gsrc + (stage * GS + i) * 256);
+        for (int i = 0; i < QS_; ++i) ws.st[i] = ldg4(gsrc + (stage * GS_ + i) * 256);
     };
     auto lwrite = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < QS; ++i)
-            *reinterpret_cast<f32x4 *>(ldst + (((stage + PH) % NSLOT) * GS + i) * 256) = ws.st[i];
+        for (int i = 0; i < QS_; ++i)
+            *reinterpret_cast<f32x4 *>(ldst + (((stage + PH) % NSLOT) * GS_ + i) * 256) = ws.st[i];
     };
     auto lread = [&](int g) {
-        return *reinterpret_cast<const f32x4 *>(lsrc + (((g / GS + PH) % NSLOT) * GS + g % GS) * 256);
+        return *reinterpret_cast<const f32x4 *>(lsrc + (((g / GS_ + PH) % NSLOT) * GS_ + g % GS_) * 256);
     };
     if (FIRST) {
         __syncthreads();
@@ -178,17 +182,17 @@ __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int g = (jb * KBT + kb) * 4 + q;
-                const int stage = g / GS, gl = g % GS;
+                const int stage = g / GS_, gl = g % GS_;
                 // The stage's staging work is spread over its first groups, one piece per group: piece i of
                 // stage+1 goes to LDS and its register is reloaded with piece i of stage+2.  Issued back to back
                 // the four 1 KiB LDS writes (and loads) of all four waves queue on the LDS/TA pipes and the wave
                 // waits; one per MFMA group is absorbed (tools/ubench/mfma_valu.hip).
-                if (gl < QS) {
-                    *reinterpret_cast<f32x4 *>(ldst + (((stage + 1 + PH) % NSLOT) * GS + gl) * 256) = ws.st[gl];
-                    ws.st[gl] = ldg4(gsrc + ((stage + 2) * GS + gl) * 256);
+                if (gl < QS_) {
+                    *reinterpret_cast<f32x4 *>(ldst + (((stage + 1 + PH) % NSLOT) * GS_ + gl) * 256) = ws.st[gl];
+                    ws.st[gl] = ldg4(gsrc + ((stage + 2) * GS_ + gl) * 256);
                 }
 #ifndef NERFMI_EXP_NOBARRIER
-                if (gl == GS / 2) __syncthreads();
+                if (gl == GS_ / 2) __syncthreads();
 #endif
                 // fragments are read ONE group ahead (two register sets): the LDS latency of group g+1 hides
                 // behind group g's four MFMAs instead of draining the pipe in front of every group

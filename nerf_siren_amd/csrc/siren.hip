@@ -222,10 +222,10 @@ int nerfmi_siren_forward_points(const float *packed, const float *points, const 
     hipStream_t st = (hipStream_t)stream;
     const bool one_cond = points_per_cond >= n_points;
     if (sigma_only)
-        SIREN_FORWARD_LAUNCH(false, true, false, grid, block, 0, st, packed, nullptr, nullptr, points,
+        SIREN_FORWARD_LAUNCH(false, true, false, grid, block, st, packed, nullptr, nullptr, points,
                            ray_directions, frequencies, phase_shifts, n_points, 1, points_per_cond, out, nullptr, (int64_t)0);
     else
-        SIREN_FORWARD_LAUNCH(false, false, false, grid, block, 0, st, packed, nullptr, nullptr, points,
+        SIREN_FORWARD_LAUNCH(false, false, false, grid, block, st, packed, nullptr, nullptr, points,
                            ray_directions, frequencies, phase_shifts, n_points, 1, points_per_cond, out, nullptr, (int64_t)0);
     return check_launch("siren_forward_points");
 }
@@ -244,10 +244,10 @@ int nerfmi_siren_forward_rays(const float *packed, const float *rays, const floa
     const bool one_cond = rays_per_cond >= n_rays;
     KernelSpan span(sigma_only ? "siren_forward_kernel<sigma_only>" : "siren_forward_kernel", n_points, st);
     if (sigma_only)
-        SIREN_FORWARD_LAUNCH(true, true, false, grid, block, 0, st, packed, rays, z, nullptr, nullptr,
+        SIREN_FORWARD_LAUNCH(true, true, false, grid, block, st, packed, rays, z, nullptr, nullptr,
                            frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out, nullptr, (int64_t)0);
     else
-        SIREN_FORWARD_LAUNCH(true, false, false, grid, block, 0, st, packed, rays, z, nullptr, nullptr,
+        SIREN_FORWARD_LAUNCH(true, false, false, grid, block, st, packed, rays, z, nullptr, nullptr,
                            frequencies, phase_shifts, n_points, n_per_ray, rays_per_cond * n_per_ray, out, nullptr, (int64_t)0);
     return check_launch("siren_forward_rays");
 }

@@ -135,11 +135,11 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
         }
         dzA[b] = v;
     }
-    __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float wlds[];       // SIREN_WLDS_BYTES
     const int wid = threadIdx.x >> 6;
-    WeightStage ws;
+    WeightStageT<SIREN_GS> ws;
     // d h_7 = W_c[:, 3:]^T dZ_c + w_sigma d sigma;  dZ_7 = d h_7 * fr_7 * cos(arg_7)      (nerf.py:212-213)
-    layer_mfma_lds<8, 0, 8, 0, true>(packed + SOFF_TCOLOR, nullptr, dzA, nullptr, dzB,
+    layer_mfma_lds<8, 0, 8, 0, true, SIREN_GS>(packed + SOFF_TCOLOR, nullptr, dzA, nullptr, dzB,
                                      [&S](int jb) { return load_cos_block(S, 7, jb); },
                                      [&](int jb, int q, f32x4 c, const f32x16 &sv) {
                                          const f32x4 w = ldg4(packed + SOFF_W_SIGMA + 32 * jb + 8 * q + 4 * half);
@@ -152,7 +152,7 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
                                      }, wlds, ws, wid, lane);
     // network.7 .. network.1: d h_{l-1} = W_l^T dZ_l;  dZ_{l-1} = d h_{l-1} * fr_{l-1} * cos(arg_{l-1})
     auto back = [&](int l, const f32x16 *in, f32x16 *out_dz) __attribute__((always_inline)) {
-        layer_mfma_lds<8, 0, 8, 0, false>(packed + SOFF_T7 + (7 - l) * SZ_HID, nullptr, in, nullptr, out_dz,
+        layer_mfma_lds<8, 0, 8, 0, false, SIREN_GS>(packed + SOFF_T7 + (7 - l) * SZ_HID, nullptr, in, nullptr, out_dz,
                                           [&S, l](int jb) { return load_cos_block(S, l - 1, jb); },
                                           [&, l](int jb, int q, f32x4 c, const f32x16 &sv) {
                                               f32x4 g;
@@ -467,7 +467,7 @@ int nerfmi_siren_forward_rays_train(const float *packed, const float *rays, cons
     const int64_t waves = (n_points + 31) / 32;
     const bool one_cond = rays_per_cond >= n_rays;
     KernelSpan span("siren_forward_kernel<save>", n_points, (hipStream_t)stream);
-    SIREN_FORWARD_LAUNCH(true, false, true, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+    SIREN_FORWARD_LAUNCH(true, false, true, dim3((unsigned)((waves + 3) / 4)), dim3(256),
                        (hipStream_t)stream, packed, rays, z, nullptr, nullptr, frequencies, phase_shifts, n_points,
                        n_per_ray, rays_per_cond * n_per_ray, out, saved, siren_pad_points(n_points));
     return check_launch("siren_forward_rays_train");
@@ -483,7 +483,7 @@ int nerfmi_siren_forward_points_train(const float *packed, const float *points, 
                    "siren_forward_points_train: null pointer");
     const int64_t waves = (n_points + 31) / 32;
     const bool one_cond = points_per_cond >= n_points;
-    SIREN_FORWARD_LAUNCH(false, false, true, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+    SIREN_FORWARD_LAUNCH(false, false, true, dim3((unsigned)((waves + 3) / 4)), dim3(256),
                        (hipStream_t)stream, packed, nullptr, nullptr, points, ray_directions, frequencies, phase_shifts,
                        n_points, 1, points_per_cond, out, saved, siren_pad_points(n_points));
     return check_launch("siren_forward_points_train");
@@ -525,6 +525,10 @@ static int siren_backward_impl(const char *who, const float *packed, const void 
                                 (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(siren_dw_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(siren_backward_chain_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SIREN_WLDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(siren_backward_chain_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SIREN_WLDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(siren_backward_chain_bf16x3_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, FLDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(siren_backward_chain_bf16x3_kernel<false>),
@@ -552,10 +556,10 @@ static int siren_backward_impl(const char *who, const float *packed, const void 
         {
             KernelSpan span("siren_backward_chain_kernel", n_points, st);
             if (one_cond)   // the workspace images hold G = dZ / fr; the reduction scales the rows (header of this file)
-                hipLaunchKernelGGL(siren_backward_chain_kernel<true>, cgrid, dim3(256), 0, st, packed, saved, grad_out, frequencies,
+                hipLaunchKernelGGL(siren_backward_chain_kernel<true>, cgrid, dim3(256), SIREN_WLDS_BYTES, st, packed, saved, grad_out, frequencies,
                                    n_points, points_per_cond, ld, work);
             else
-                hipLaunchKernelGGL(siren_backward_chain_kernel<false>, cgrid, dim3(256), 0, st, packed, saved, grad_out,
+                hipLaunchKernelGGL(siren_backward_chain_kernel<false>, cgrid, dim3(256), SIREN_WLDS_BYTES, st, packed, saved, grad_out,
                                    frequencies, n_points, points_per_cond, ld, work);
         }
         KernelSpan span("siren_dw_kernel", n_points, st);

@@ -29,13 +29,24 @@ constexpr int SOFF_TRANS = (SOFF_B_RGB + 4 + 255) / 256 * 256;
 constexpr int SOFF_TCOLOR = SOFF_TRANS;             // 8 kbo x 8 jb
 constexpr int SOFF_T7 = SOFF_TCOLOR + SZ_HID;       // network.l at SOFF_T7 + (7 - l) * SZ_HID, l = 7..1
 // readable tail: the weight streams prefetch two stages past their last layer
-constexpr int SIREN_PACKED_FLOATS = SOFF_T7 + 7 * SZ_HID + STREAM_TAIL;
+// stage length of the weight ring in the fp32 FiLM-SIREN kernels (mlp_core.h layer_mfma_lds; every layer of this field is a
+// whole number of 8-, 16- or 32-fragment stages).  Measured on MI355X, same box (round 3): 8 fragments (twice the workgroup
+// barriers) forward-with-save +1.6 %, chain +0.0 %; 32 fragments (half the barriers) +9.5 % / +12.8 %, because the 32 staging
+// registers no longer fit beside the two activation buffers (380 VGPR <-> AGPR moves): the barriers are not where the time goes
+#ifndef NERFMI_SIREN_GS
+#define NERFMI_SIREN_GS 16
+#endif
+constexpr int SIREN_GS = NERFMI_SIREN_GS;
+constexpr int SIREN_PH = (32 / SIREN_GS) % NSLOT;      // ring phase behind network.0 (32 fragments); the hidden layers keep it
+constexpr int SIREN_WLDS_BYTES = NSLOT * SIREN_GS * 1024;
+constexpr int SIREN_STREAM_TAIL = 2 * SIREN_GS * 256;
+constexpr int SIREN_PACKED_FLOATS = SOFF_T7 + 7 * SZ_HID + SIREN_STREAM_TAIL;
 // split-bf16 image (bf16x3_core.h): a unit = 512 floats of `packed` = 3 x 1 KiB; the forward layers' units, then the eight
 // transposed images of the backward chain in the order it walks them
 constexpr int SIREN_FAST_FWD_UNITS = SOFF_BIAS / 512;
 constexpr int SIREN_FAST_UNITS = SIREN_FAST_FWD_UNITS + 8 * (SZ_HID / 512);
 constexpr int SIREN_N_PARAMS = 22;  // network.{0..7}.layer.{weight,bias}, final_layer.*, color_layer_sine.layer.*, color_layer_linear.0.*
-static_assert(SOFF_TRANS - SOFF_BIAS + 8 * SZ_HID >= 2 * GS * 256, "the forward stream's prefetch stays inside the image");
+static_assert(SOFF_TRANS - SOFF_BIAS + 8 * SZ_HID >= 2 * SIREN_GS * 256, "the forward stream's prefetch stays inside the image");
 
 // Activations kept for training: tile-major images, same row map in two element orders:
 //   fp32 path (siren_forward_kernel<save>, siren_backward_chain_kernel, siren_dw_kernel): the "x4" order (mlp_core.h at4 /
@@ -191,7 +202,7 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
         };
     };
     auto no_pre = [](int) { return 0; };
-    __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float wlds[];     // SIREN_WLDS_BYTES (dynamic: may exceed the 64 KiB static limit)
     const int wid = threadIdx.x >> 6;
     // the nine layers' biases staged in LDS: an L2-latency bias load sits right in front of each block's first MFMA
     // (measured here: training step 5.77 -> 5.71 ms; the same change made the NeRF kernels 1 % SLOWER and is not in mlp.hip)
@@ -199,11 +210,11 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
     for (int i = threadIdx.x; i < 9 * 256; i += blockDim.x) lbias[i] = packed[SOFF_BIAS + i];
     const float *bias = lbias + 4 * half;
     f32x16 hA[8], hB[8];                   // alternate: a layer reads one, its epilogue writes the other (no copies)
-    WeightStage ws;
-    // ring phases: network.0 is 2 stages, every hidden layer 16, so the hidden and color layers start at phase 2
-    layer_mfma_lds<1, 0, 8, 0, true>(packed + SOFF_L1, bias, e, nullptr, hA, no_pre, film_epi(0), wlds, ws, wid, lane);
+    WeightStageT<SIREN_GS> ws;
+    // ring phases: network.0 is 32 fragments, every hidden layer a multiple of four stages: the hidden and color layers start at SIREN_PH
+    layer_mfma_lds<1, 0, 8, 0, true, SIREN_GS>(packed + SOFF_L1, bias, e, nullptr, hA, no_pre, film_epi(0), wlds, ws, wid, lane);
     auto hidden = [&](int l, const f32x16 *in, f32x16 *out_h) __attribute__((always_inline)) {
-        layer_mfma_lds<8, 0, 8, 2, false>(packed + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, in, nullptr, out_h, no_pre,
+        layer_mfma_lds<8, 0, 8, SIREN_PH, false, SIREN_GS>(packed + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, in, nullptr, out_h, no_pre,
                                           film_epi(l), wlds, ws, wid, lane);
     };
     hidden(1, hA, hB);
@@ -218,7 +229,7 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
         if (ok && half == 0) out[p] = sigma;
         return;
     }
-    layer_mfma_lds<1, 8, 8, 2, false>(packed + SOFF_COLOR, bias + 256 * 8, de, hB, hA, no_pre, film_epi(8), wlds, ws, wid, lane);            // nerf.py:213
+    layer_mfma_lds<1, 8, 8, SIREN_PH, false, SIREN_GS>(packed + SOFF_COLOR, bias + 256 * 8, de, hB, hA, no_pre, film_epi(8), wlds, ws, wid, lane);            // nerf.py:213
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -239,11 +250,37 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
 
 static inline int64_t siren_pad_points(int64_t n) { return (n + 31) / 32 * 32; }
 
+// the weight ring is dynamic LDS (SIREN_WLDS_BYTES may exceed the 64 KiB default limit): raise the limit of the two instances a
+// launch may pick, once per device
+template <bool FROM_RAYS, bool SIGMA_ONLY, bool SAVE>
+static inline bool siren_forward_lds_ok() {
+    static PerDeviceOnce once;
+    int dev;
+    if (!once.needed(dev)) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(siren_forward_kernel<FROM_RAYS, SIGMA_ONLY, SAVE, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SIREN_WLDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(siren_forward_kernel<FROM_RAYS, SIGMA_ONLY, SAVE, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SIREN_WLDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    once.mark(dev);
+    return true;
+}
+
 // the launch shares ONE conditioning row (`one_cond` in scope): FiLM constants through LDS, else per-lane rows from memory
-#define SIREN_FORWARD_LAUNCH(FROM_RAYS, SIGMA_ONLY, SAVE, ...)                                                        \
+#define SIREN_FORWARD_LAUNCH(FROM_RAYS, SIGMA_ONLY, SAVE, grid, block, stream, ...)                                    \
     do {                                                                                                              \
-        if (one_cond) hipLaunchKernelGGL((siren_forward_kernel<FROM_RAYS, SIGMA_ONLY, SAVE, true>), __VA_ARGS__);      \
-        else hipLaunchKernelGGL((siren_forward_kernel<FROM_RAYS, SIGMA_ONLY, SAVE, false>), __VA_ARGS__);              \
+        if (!siren_forward_lds_ok<FROM_RAYS, SIGMA_ONLY, SAVE>()) {                                                   \
+            set_error("siren forward: cannot raise the dynamic LDS limit");                                           \
+            return NERFMI_E_LAUNCH;                                                                                   \
+        }                                                                                                             \
+        if (one_cond)                                                                                                 \
+            hipLaunchKernelGGL((siren_forward_kernel<FROM_RAYS, SIGMA_ONLY, SAVE, true>), grid, block, SIREN_WLDS_BYTES, stream, \
+                               __VA_ARGS__);                                                                          \
+        else                                                                                                          \
+            hipLaunchKernelGGL((siren_forward_kernel<FROM_RAYS, SIGMA_ONLY, SAVE, false>), grid, block, SIREN_WLDS_BYTES, stream, \
+                               __VA_ARGS__);                                                                          \
     } while (0)
 
 }  // namespace nerfmi
