@@ -49,7 +49,7 @@ def _worker(rank, world, port, q):
     bases = red.all_reduce()
     assert len(bases) == 1 and bases[0].data_ptr() == flat1.data_ptr() and bases[0].numel() == flat1.numel()
     flat = torch.cat([p.grad.reshape(-1) for m in models for p in m.parameters()])
-    q.put((rank, flat))
+    q.put((rank, flat.numpy()))       # by value: a tensor travels as a file descriptor the parent must fetch while this process lives
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,7 +63,7 @@ def test_flat_grad_allreduce_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=90) for _ in range(world))
+    got = {r: torch.from_numpy(v) for r, v in (q.get(timeout=90) for _ in range(world))}
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
@@ -100,7 +100,7 @@ def _worker_uneven(rank, world, port, q, n, mode):
     else:
         _loss(models, rays[shard_indices(n, rank, world)]).backward()
     red.all_reduce()
-    q.put((rank, torch.cat([p.grad.reshape(-1) for m in models for p in m.parameters()])))
+    q.put((rank, torch.cat([p.grad.reshape(-1) for m in models for p in m.parameters()]).numpy()))   # by value (see _worker)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -112,7 +112,7 @@ def _run_world(target, world, *args):
     procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=150) for _ in range(world))
+    got = {r: torch.from_numpy(v) for r, v in (q.get(timeout=150) for _ in range(world))}
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
