@@ -106,8 +106,9 @@ int nerfmi_nerf_pack_fast(const float *packed, void *fast, nerfmi_stream_t strea
 int nerfmi_nerf_forward_rays_fast(const float *packed, const void *fast, const float *rays, const float *z,
                                   int n_rays, int n_per_ray, int sigma_only, float *out, float *saved,
                                   nerfmi_stream_t stream);
-/* nerfmi_nerf_backward_rays with the dX chain on the split-bf16 path (the dW GEMM and the slab reduction are the
- * fp32 kernels); same saved / workspace buffers. */
+/* nerfmi_nerf_backward_rays with the dX chain and the 256 x 256 dW tasks on the split-bf16 path; same saved / workspace sizes.
+ * A `saved` image is OPAQUE and belongs to the math that wrote it (the two paths order the elements of a 32-point tile
+ * differently): nerfmi_nerf_forward_rays[/_embedded_train] -> nerfmi_nerf_backward_rays, _forward_rays_fast -> _backward_rays_fast. */
 int nerfmi_nerf_backward_rays_fast(const float *packed, const void *fast, int n_rays, int n_per_ray, const float *saved,
                                    const float *grad_out, float *const *grad_params, float *workspace,
                                    nerfmi_stream_t stream);

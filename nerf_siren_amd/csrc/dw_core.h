@@ -184,24 +184,26 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
 // ds_read_b128 pass (consecutive row groups, one point) start 16 B apart inside a piece and 1056 B = 8 banks + 16 rows
 // apart across pieces: 16 different 4-bank groups.  All of the next tile's pieces are issued in the first half of the
 // current tile's steps, so that the vmcnt(0) the barrier at the tile's end needs finds them landed.
-//   kind 0  256 x 256 : IA = 4, JB4 = 4, waves 2 (A sets) x 2 (B sets)
-//   kind 1  256 x 3   : the three input columns sit in unit 0 of row groups 0..2 (rows 0, 4, 8): IA = 4, JB4 = 1; waves
-//                       2 (A sets) x 2 (halves of the tile's points, written as two slabs: the reduction sums slabs anyway)
-//   kind 2  3 x 256   : the head's dZ rows sit in unit 0 of row groups 0..2: IA = 1, JB4 = 4; waves 2 (B sets) x 2 (point halves)
+// Forms (IA / JB4 = 4: all four units of 32 row groups per wave set, WA / WB sets of 128 rows; = 1: unit 0 only -- a narrow
+// operand whose few rows sit in unit 0 of their own row groups; WP = point ranges of a tile handled by different waves, each
+// writing its own slab: the reduction sums slabs anyway; NA_P / NB_P = 1 KiB pieces (8 rows) that really exist and are staged,
+// the lanes past them multiply whatever the LDS holds into rows / columns the reduction drops):
+//   FiLM-SIREN  256 x 256 <4,4,2,2,1,32,32>   256 x 3 (x, y, z / direction) <4,1,2,1,2,32,2>   heads 3 x 256 <1,4,1,2,2,2,32>
+//   NeRF        256 x 256 <4,4,2,2,1,32,32>   256 x 63 (embedding) <4,4,2,1,2,32,8>   128 x 256 <4,4,1,2,2,16,32>
+//               128 x 27 (direction embedding) <4,4,1,1,4,16,4>   rgb 3 x 128 <1,4,1,1,4,2,16>   sigma 1 x 256 <1,4,1,2,2,2,32>
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) void gbl_void_t;
 
-template <int IA, int JB4, int WA, int WB, int WP, int AROWS, int BROWS>
+template <int IA, int JB4, int WA, int WB, int WP, int NA_P, int NB_P, int AROWS, int BROWS>
 __device__ __forceinline__ void dw_task4g(const DwTask &T, int chunk, const float *__restrict__ work,
                                           const float *__restrict__ saved, int64_t ld, float *__restrict__ partial,
                                           float *lds) {
     static_assert(WA * WB * WP == 4, "four waves per workgroup");
     constexpr int PIECE = 1056;                           // LDS bytes between pieces (1 KiB + 32: see above)
-    constexpr int NA_P = (IA == 4) ? WA * 16 : 2;         // pieces staged per tile
-    constexpr int NB_P = (JB4 == 4) ? WB * 16 : 2;
-    constexpr int A_AL = NA_P < 16 ? 16 : NA_P;           // a wave's 32 lanes read 32 row groups: keep the reads inside LDS
-    constexpr int B_AL = NB_P < 16 ? 16 : NB_P;
+    constexpr int A_AL = (IA == 4) ? WA * 16 : 16;        // a wave's 32 lanes read 32 row groups: keep the reads inside LDS
+    constexpr int B_AL = (JB4 == 4) ? WB * 16 : 16;
+    static_assert(NA_P <= A_AL && NB_P <= B_AL, "staged pieces fit their region");
     constexpr int BUF_BYTES = (A_AL + B_AL) * PIECE;
     constexpr bool A_FIRST = NA_P >= NB_P;                // piece order of a tile: the wide operand first
     constexpr int NP = NA_P + NB_P, NJ = (NP + 3) / 4;    // pieces per tile, per wave

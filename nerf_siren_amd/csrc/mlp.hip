@@ -181,9 +181,10 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         if (!SIGMA_ONLY) embed_dir_block(rr[3], rr[4], rr[5], half, de[0]);
     }
     if (SAVE) {
-        store_block(S, S_EMB, e[0]);
-        store_block(S, S_EMB + 32, e[1]);
-        store_block(S, S_DEMB, de[0]);
+        // x4 element order (mlp_core.h store_slice4): what the fp32 dW GEMM (dw_core.h dw_task4g) stages by LDS-DMA
+        store_block4(S, S_EMB, e[0]);
+        store_block4(S, S_EMB + 32, e[1]);
+        store_block4(S, S_DEMB, de[0]);
     }
 
     __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
@@ -210,7 +211,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
                 mask_or(mk, jb, q, c);
 #endif
 #ifndef NERFMI_EXP_NOSTORE
-                store_slice(S, row0 + 32 * jb, q, c);
+                store_slice4(S, row0 + 32 * jb, q, c);
 #endif
             }
             return c;
@@ -242,7 +243,7 @@ nerf_forward_kernel(const float *__restrict__ packed, const float *__restrict__ 
         // xyz_encoding_final: no activation (nerf.py:116)
         layer_mfma_lds<8, 0, 8, 0, false>(packed + OFF_FINAL, bias + 256 * 8, hB, nullptr, hA, no_pre,
                                           [&S](int jb, int q, f32x4 c, int) {
-                                              if (SAVE) store_slice(S, S_FINAL + 32 * jb, q, c);
+                                              if (SAVE) store_slice4(S, S_FINAL + 32 * jb, q, c);
                                               return c;
                                           }, wlds, ws, wid, lane);
         NERFMI_TS(10);

@@ -25,9 +25,12 @@ namespace nerfmi {
 constexpr int W_DZ = 0;                  // 8 x 256: dZ of xyz_encoding_1..8 (masked by ReLU)
 constexpr int W_DFINAL = 8 * 256;        // 256: d xyz_encoding_final output
 constexpr int W_DDIR = W_DFINAL + 256;   // 128: dZ of dir_encoding
-constexpr int W_DRGB = W_DDIR + 128;     // 3 (+1 pad): d rgb pre-sigmoid
-constexpr int W_DSIG = W_DRGB + 4;       // 1 (+3 pad): d sigma
-constexpr int W_ROWS = W_DSIG + 4;
+// head rows: [row][32 points] order in the split-bf16 chain (rows W_DRGB + c, W_DSIG); x4 order in the fp32 chain, where they sit
+// in unit 0 of their own row groups (rows W_DRGB + 4c, W_DSIG4) for dw_task4g's narrow-A form (two pieces = 16 rows each)
+constexpr int W_DRGB = W_DDIR + 128;     // d rgb pre-sigmoid
+constexpr int W_DSIG = W_DRGB + 4;       // d sigma ([row][point] order)
+constexpr int W_DSIG4 = W_DRGB + 16;     // d sigma (x4 order)
+constexpr int W_ROWS = W_DRGB + 32;
 
 // ---------------------------------------------------------------------------
 // 1. dX chain
@@ -57,9 +60,9 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
         for (int c = 0; c < 3; ++c) {
             const float rgb = *S.at(S_RGB + c);
             dpre[c] = g3[c] * rgb * (1.0f - rgb);
-            if (half == 0) *Wk.at(W_DRGB + c) = dpre[c];
+            if (half == 0) *at4(Wk, W_DRGB + 4 * c) = dpre[c];
         }
-        if (half == 0) *Wk.at(W_DSIG) = go.w;
+        if (half == 0) *at4(Wk, W_DSIG4) = go.w;
     }
     const float dsig = go.w;
 
@@ -83,7 +86,7 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
             }
         }
         dzA[b] = v;
-        store_block(Wk, W_DDIR + 32 * b, v);
+        store_block4(Wk, W_DDIR + 32 * b, v);
     }
     __shared__ __attribute__((aligned(16))) float wlds[WLDS_FLOATS];
     const int wid = threadIdx.x >> 6;
@@ -92,7 +95,7 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
     // d final = W_dir[:, :256]^T dZ_dir                          (nerf.py:116-118; no activation on final)
     layer_mfma_lds<4, 0, 8, 0, true>(packed + OFF_TDIR, nullptr, dzA, nullptr, dzB, zero_pre,
                             [&Wk](int jb, int q, f32x4 c, int) {
-                                store_slice(Wk, W_DFINAL + 32 * jb, q, c);
+                                store_slice4(Wk, W_DFINAL + 32 * jb, q, c);
                                 return c;
                             }, wlds, ws, wid, lane);
     // d h8 = W_final^T d final + w_sigma d sigma, masked by h8 > 0 (nerf.py:112-116)
@@ -105,7 +108,7 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
                                      const float v = __builtin_fmaf(w[t], dsig, c[t]);
                                      c[t] = mask_keep(mk, jb, q, t, v);
                                  }
-                                 store_slice(Wk, W_DZ + 7 * 256 + 32 * jb, q, c);
+                                 store_slice4(Wk, W_DZ + 7 * 256 + 32 * jb, q, c);
                                  return c;
                              }, wlds, ws, wid, lane);
     // xyz_encoding_8 .. xyz_encoding_2: d h_{l-1} = W_l[:, hidden]^T dZ_l, masked by h_{l-1} > 0
@@ -116,7 +119,7 @@ nerf_backward_chain_kernel(const float *__restrict__ packed, const float *__rest
                                  [&](int jb, int q, f32x4 c, int) {
 #pragma unroll
                                      for (int t = 0; t < 4; ++t) c[t] = mask_keep(mk, jb, q, t, c[t]);
-                                     store_slice(Wk, wrow + 32 * jb, q, c);
+                                     store_slice4(Wk, wrow + 32 * jb, q, c);
                                      return c;
                                  }, wlds, ws, wid, lane);
     };
@@ -282,12 +285,13 @@ nerf_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__restr
     const DwTask T = plan.t[ti];
     const int chunk = blockIdx.x - T.wg0;
     switch (T.kind) {
-        case 0: dw_task<2, 8, 4, 1, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;
-        case 1: dw_task<2, 2, 4, 1, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;
-        case 2: dw_task<1, 8, 4, 1, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;
-        case 3: dw_task<1, 1, 4, 1, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;
-        case 4: dw_task<1, 1, 1, 4, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;
-        default: dw_task<1, 2, 1, 4, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;
+        // dw_core.h dw_task4g<IA, JB4, WA, WB, WP, NA_P, NB_P> on the x4 images of the fp32 forward / chain
+        case 0: dw_task4g<4, 4, 2, 2, 1, 32, 32, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 256
+        case 1: dw_task4g<4, 4, 2, 1, 2, 32, 8, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;    // 256 x 63 (xyz embedding)
+        case 2: dw_task4g<4, 4, 1, 2, 2, 16, 32, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 128 x 256
+        case 3: dw_task4g<4, 4, 1, 1, 4, 16, 4, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;    // 128 x 27 (dir embedding)
+        case 4: dw_task4g<1, 4, 1, 1, 4, 2, 16, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;    // rgb 3 x 128
+        default: dw_task4g<1, 4, 1, 2, 2, 2, 32, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // sigma 1 x 256
     }
 #ifdef NERFMI_TIMING
     if (threadIdx.x == 0) nerfmi_dbg_dw[blockIdx.x] = __builtin_readcyclecounter() - t_start;
@@ -296,8 +300,11 @@ nerf_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__restr
 
 // 3. slab reduction: dw_core.h
 
+// slab = 32 JB rows x 32 KB columns per kind: fp32 plan (dw_task4g forms above) / split-bf16 plan ([row][point] tasks)
 static const int KIND_JB[6] = {8, 8, 4, 4, 1, 1};
-static const int KIND_KB[6] = {8, 2, 8, 1, 4, 8};
+static const int KIND_KB[6] = {8, 4, 8, 4, 4, 8};
+static const int KIND_WP[6] = {1, 2, 2, 4, 4, 2};      // slabs per workgroup (point ranges of a tile handled by different waves)
+static const int KIND_KB_FAST[6] = {8, 2, 8, 1, 4, 8};
 
 static DwPlan make_plan(int64_t ld, bool fast = false) {
     DwPlan P;
@@ -305,8 +312,8 @@ static DwPlan make_plan(int64_t ld, bool fast = false) {
     auto add = [&](int kind, int a_row0, int a_valid, int b_row0, int b_valid, int param, int col0, int in_f, int bias) {
         DwTask &t = P.t[n++];
         t.kind = kind; t.a_row0 = a_row0; t.a_valid = a_valid; t.b_row0 = b_row0; t.b_valid = b_valid;
-        t.param = param; t.out_col0 = col0; t.in_f = in_f; t.bias_param = bias; t.wp = 1;
-        t.JB = KIND_JB[kind]; t.KB = KIND_KB[kind];
+        t.param = param; t.out_col0 = col0; t.in_f = in_f; t.bias_param = bias; t.wp = fast ? 1 : KIND_WP[kind];
+        t.JB = KIND_JB[kind]; t.KB = fast ? KIND_KB_FAST[kind] : KIND_KB[kind];
     };
     add(1, W_DZ, 256, S_EMB, 63, 0, 0, 63, 1);                                       // xyz_encoding_1
     for (int li = 1; li <= 3; ++li) add(0, W_DZ + 256 * li, 256, S_H + 256 * (li - 1), 256, 2 * li, 0, 256, 2 * li + 1);
@@ -317,14 +324,15 @@ static DwPlan make_plan(int64_t ld, bool fast = false) {
     add(2, W_DDIR, 128, S_FINAL, 256, 18, 0, 283, 19);                               // dir_encoding, final part
     add(3, W_DDIR, 128, S_DEMB, 27, 18, 256, 283, -1);                               // dir_encoding, dir-emb part
     add(4, W_DRGB, 3, S_DIRH, 128, PARAM_RGB_W, 0, 128, PARAM_RGB_B);                // rgb
-    add(5, W_DSIG, 1, S_H + 256 * 7, 256, PARAM_SIGMA_W, 0, 256, PARAM_SIGMA_B);     // sigma
+    add(5, fast ? W_DSIG : W_DSIG4, 1, S_H + 256 * 7, 256, PARAM_SIGMA_W, 0, 256, PARAM_SIGMA_B);     // sigma
     P.n_tasks = n;
-    // chunks proportional to MFMA work so that every workgroup costs the same and the grid is <= 256 (one per CU)
-    // cost per 32-point tile ~ MFMA cycles + ~1.5k cycles of staging/barriers (measured: the small tasks were
-    // the critical path when sized by MFMA work alone)
-    // 8 x 26 + 2 x 9 + 14 + 5 + 5 + 6 = 256 workgroups: every CU gets exactly one (the LDS tiles of a workgroup
-    // fill a CU), so the kernel takes one workgroup's time; leaving CUs without a chunk costs their share outright
-    static const int base_fp32[6] = {26, 9, 14, 5, 5, 6};
+    // chunks proportional to the measured cost of a task (per-workgroup shader-clock stamps, tools/exp_dw_timing.py ... fp32:
+    // 71.8 / 36.6 / 37.0 / 18.5 / 8.9 / 12.4 M cycles per task of kinds 0..5 at 4096 tiles), so that every workgroup costs the
+    // same and the grid is exactly 256 (one per CU: the LDS tiles of a workgroup fill a CU, so the kernel takes one workgroup's
+    // time, and leaving CUs without a chunk costs their share outright): 8 x 25 + 2 x 13 + 13 + 8 + 4 + 5 = 256.
+    // The embedding tasks (kind 1, 3) fill only half / a quarter of their 32 B lanes and the two heads are bound by the
+    // latency of their tile loads, not by their 16-32 MFMAs per tile: together 10 % of the kernel is spent there.
+    static const int base_fp32[6] = {25, 13, 13, 8, 4, 5};
     // split-bf16 variant: the 256 x 256 tasks run ~2x faster per tile, so the fp32 tasks get the larger share of CUs:
     // 8 x 24 + 2 x 12 + 18 + 6 + 6 + 10 = 256, from measured per-task workgroup times (tools/exp_dw_timing.py:
     // 38.2 / 18.5 / 25.5 / 8.4 / 8.5 / 12.6 M cycles per task at 4096 tiles); the tiny tasks 3..5 stay on the fp32 path
@@ -347,9 +355,9 @@ static DwPlan make_plan(int64_t ld, bool fast = false) {
         DwTask &t = P.t[i];
         int c = base[t.kind];
         if (c > tiles) c = (int)(tiles < 1 ? 1 : tiles);
-        t.chunks = c; t.wg0 = wg; t.part_off = off;
+        t.chunks = c * t.wp; t.wg0 = wg; t.part_off = off;
         wg += c;
-        off += c * (t.JB * 32 * (t.KB * 32 + 1));
+        off += c * t.wp * (t.JB * 32 * (t.KB * 32 + 1));
     }
     P.n_wg = wg;
     return P;

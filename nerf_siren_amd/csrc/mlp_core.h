@@ -282,6 +282,10 @@ __device__ __forceinline__ void store_slice4(const RowImage &im, int row0, int q
     float *dst = im.tile + (((row0 + 8 * q) >> 2) + (im.lane >> 5)) * 128 + (im.lane & 31) * 4;
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));       // streamed once, read back by a later kernel
 }
+__device__ __forceinline__ void store_block4(const RowImage &im, int row0, const f32x16 &v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_slice4(im, row0, q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+}
 __device__ __forceinline__ void store_block(const RowImage &im, int row0, const f32x16 &v) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) store_slice(im, row0, q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});

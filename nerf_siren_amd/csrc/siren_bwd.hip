@@ -296,9 +296,9 @@ siren_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__rest
     const int chunk = blockIdx.x - T.wg0;
     switch (T.kind) {
         // dw_core.h dw_task4g<IA, JB4, WA, WB, WP>
-        case 0: dw_task4g<4, 4, 2, 2, 1, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 256
-        case 1: dw_task4g<4, 1, 2, 1, 2, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 3 (x, y, z / direction)
-        default: dw_task4g<1, 4, 1, 2, 2, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;  // 3 x 256 (heads)
+        case 0: dw_task4g<4, 4, 2, 2, 1, 32, 32, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 256
+        case 1: dw_task4g<4, 1, 2, 1, 2, 32, 2, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 3 (x, y, z / direction)
+        default: dw_task4g<1, 4, 1, 2, 2, 2, 32, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;  // 3 x 256 (heads)
     }
 #ifdef NERFMI_TIMING
     if (threadIdx.x == 0) nerfmi_dbg_siren_dw[blockIdx.x] = __builtin_readcyclecounter() - t_start;

@@ -269,6 +269,8 @@ def nerf_forward_rays(packed, rays, z, sigma_only=False, save=False):
     with _Span("nerf_forward_rays", p):
         check(_lib.lib().nerfmi_nerf_forward_rays(ptr(packed), ptr(rays), ptr(z), n, p, int(bool(sigma_only)), ptr(out),
                                                   ptr(saved), _stream(rays)), "nerf_forward_rays")
+    if save:
+        saved._nerfmi_math = "f32"        # the fp32 and split-bf16 paths keep their images in different element orders
     return (out, saved) if save else out
 
 
@@ -289,6 +291,8 @@ def nerf_forward_rays_fast(packed, fast, rays, z, sigma_only=False, save=False):
         check(_lib.lib().nerfmi_nerf_forward_rays_fast(ptr(packed), ptr(fast), ptr(rays), ptr(z), n, p,
                                                        int(bool(sigma_only)), ptr(out), ptr(saved), _stream(rays)),
               "nerf_forward_rays_fast")
+    if save:
+        saved._nerfmi_math = "bf16x3"
     return (out, saved) if save else out
 
 
@@ -310,6 +314,7 @@ def nerf_forward_embedded_train(packed, x):
     saved = torch.empty(nerf_saved_floats(n), device=x.device, dtype=torch.float32)
     check(_lib.lib().nerfmi_nerf_forward_embedded_train(ptr(packed), ptr(x), n, ptr(out), ptr(saved), _stream(x)),
           "nerf_forward_embedded_train")
+    saved._nerfmi_math = "f32"
     return out, saved
 
 
@@ -336,6 +341,9 @@ def nerf_backward_rays(packed, rays, z, saved, grad_out, grads=None, fast=None):
         grads = flat_views(torch.empty(PARAM_NUMEL, device=rays.device, dtype=torch.float32))
     ws = torch.empty(_lib.lib().nerfmi_nerf_backward_workspace_floats(n * p), device=rays.device,
                      dtype=torch.float32)
+    if getattr(saved, "_nerfmi_math", None) not in (None, "f32" if fast is None else "bf16x3"):
+        raise ValueError("nerf_backward_rays: the saved image was written by the %s forward; its backward must use the same math "
+                         "(the fp32 and split-bf16 paths order the image differently)" % saved._nerfmi_math)
     if fast is not None:
         check(_lib.lib().nerfmi_nerf_backward_rays_fast(ptr(packed), ptr(fast), n, p, ptr(saved), ptr(grad_out),
                                                         _ptr_array(grads), ptr(ws), _stream(rays)),

@@ -37,10 +37,19 @@ def reference_masks(g, mi, cache):
     return m, flips
 
 
-def hip_masks(saved, n_points):
-    """ReLU masks of the HIP forward from its saved-activation image (tile-major [tile of 32 points][row][32])."""
+def hip_masks(saved, n_points, order=None):
+    """ReLU masks of the HIP forward from its saved-activation image (tile-major: one tile per 32 points).  Inside a tile
+    the fp32 path keeps the "x4" element order (row r, point p at ((r >> 2) * 32 + p) * 4 + (r & 3); csrc/mlp_core.h at4),
+    the split-bf16 path [row][32 points].  `saved`: the tensor the ops layer returned (it carries its order as
+    `_nerfmi_math`) or an array with order = "x4" | "rows"."""
+    if order is None:
+        order = {"f32": "x4", "bf16x3": "rows", None: "x4"}[getattr(saved, "_nerfmi_math", None)]
+    arr = saved.detach().cpu().numpy() if hasattr(saved, "detach") else np.asarray(saved)
     ld = (n_points + 31) // 32 * 32
-    img = np.asarray(saved)[: SAVED_ROWS * ld].reshape(ld // 32, SAVED_ROWS, 32).transpose(1, 0, 2).reshape(SAVED_ROWS, ld)
+    tiles = arr[: SAVED_ROWS * ld].reshape(ld // 32, SAVED_ROWS * 32)
+    if order == "x4":
+        tiles = tiles.reshape(ld // 32, SAVED_ROWS // 4, 32, 4).transpose(0, 1, 3, 2)
+    img = tiles.reshape(ld // 32, SAVED_ROWS, 32).transpose(1, 0, 2).reshape(SAVED_ROWS, ld)
     img = img[:, :n_points]
     return {"h": [img[S_H + 256 * l: S_H + 256 * (l + 1)].T > 0 for l in range(8)], "dir": img[S_DIRH: S_DIRH + 128].T > 0}
 
