@@ -326,6 +326,111 @@ __device__ __forceinline__ void dw_task4g(const DwTask &T, int chunk, const floa
     }
 }
 
+// The same GEMM for a B operand of at most 64 rows (the NeRF embeddings: 63 / 27 columns of dW), on v_mfma_f32_16x16x4_f32:
+// in the 32-lane form above such an operand fills half (a quarter) of the 32 B lanes and every MFMA wastes that share of
+// its work.  Here a wave's A set and the B set are 16 row groups each: lane l reads the 16-byte word (row group l & 15, point
+// 4 s + (l >> 4)), unit i of it is operand A_i / B_j of a 16 x 16 x 4 MFMA (same FLOP per cycle as 32 x 32 x 2), the 4 x 4 products
+// fill a 64 x 64 tile of dW, a step covers four points, a tile eight steps.  Waves: WA A sets (64 rows each) x WP point
+// ranges; same staging, same slab format.   256 x 63 <4, 1, 32, 8>   128 x 27 <2, 2, 16, 4>
+template <int WA, int WP, int NA_P, int NB_P, int AROWS, int BROWS>
+__device__ __forceinline__ void dw_task4g16(const DwTask &T, int chunk, const float *__restrict__ work,
+                                            const float *__restrict__ saved, int64_t ld, float *__restrict__ partial,
+                                            float *lds) {
+    static_assert(WA * WP == 4, "four waves per workgroup");
+    constexpr int PIECE = 1056;
+    constexpr int A_AL = WA * 8, B_AL = 8;                // pieces of LDS per operand: 16 row groups per set
+    static_assert(NA_P <= A_AL && NB_P <= B_AL && NA_P >= NB_P && NA_P % 4 == 0 && NB_P % 4 == 0, "piece counts");
+    constexpr int BUF_BYTES = (A_AL + B_AL) * PIECE;
+    constexpr int NJ = (NA_P + NB_P) / 4;                 // pieces per tile per wave: the A pieces, then the B pieces
+    constexpr int STEPS = 8 / WP;
+    constexpr int ISSUE_STEPS = STEPS / 2;
+    constexpr int PER_STEP = (NJ + ISSUE_STEPS - 1) / ISSUE_STEPS;
+    const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wid % WA, wp = wid / WA;
+    const int wg_chunks = T.chunks / WP;
+    const int64_t tiles = ld / 32;
+    const int64_t t_lo = tiles * chunk / wg_chunks, t_hi = tiles * (chunk + 1) / wg_chunks;
+    const char *abase = reinterpret_cast<const char *>(work + (int64_t)T.a_row0 * 32);
+    const char *bbase = reinterpret_cast<const char *>(saved + (int64_t)T.b_row0 * 32);
+    char *lbase = reinterpret_cast<char *>(lds);
+    const unsigned poff = (unsigned)((lane & 1) * 512 + (lane >> 1) * 16);
+    auto issue = [&](int j, const char *sa, const char *sb, char *buf) __attribute__((always_inline)) {
+        const bool is_a = j < NA_P / 4;                   // compile-time after unrolling
+        const int p = is_a ? 4 * j + wid : 4 * (j - NA_P / 4) + wid;
+        const char *src = (is_a ? sa : sb) + p * 1024;
+        char *dst = buf + (is_a ? 0 : A_AL * PIECE) + p * PIECE;
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + poff), (lds_void_t *)dst, 16, 0, 0);
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x2 bsum2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+    if (t_lo < t_hi) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) issue(j, abase + t_lo * (int64_t)(AROWS * 128), bbase + t_lo * (int64_t)(BROWS * 128), lbase);
+    }
+    __syncthreads();
+    // (row group g, point 4 s + kq) at piece (g >> 1), slot 2 (4 s + kq) + (g & 1): 128 bytes per step
+    const int rga = wa * 16 + (lane & 15), rgb = lane & 15;
+    const unsigned a_off = (unsigned)((rga >> 1) * PIECE + (rga & 1) * 16 + kq * 32 + STEPS * wp * 128);
+    const unsigned b_off = (unsigned)(A_AL * PIECE + (rgb >> 1) * PIECE + (rgb & 1) * 16 + kq * 32 + STEPS * wp * 128);
+    int cur = 0;
+    for (int64_t t = t_lo; t < t_hi; ++t) {
+        const int64_t t1 = (t + 1 < t_hi) ? t + 1 : t_hi - 1;
+        const char *sa = abase + t1 * (int64_t)(AROWS * 128), *sb = bbase + t1 * (int64_t)(BROWS * 128);
+        const char *ca = lbase + cur + a_off, *cb = lbase + cur + b_off;
+        char *nxt = lbase + (BUF_BYTES - cur);
+        f32x4 a = *reinterpret_cast<const f32x4 *>(ca), b = *reinterpret_cast<const f32x4 *>(cb);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(bsum2[0]) : "v"(f32x2{a[0], a[1]}));
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(bsum2[1]) : "v"(f32x2{a[2], a[3]}));
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                acc[m / 4][m % 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m / 4], b[m % 4], acc[m / 4][m % 4], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 an = a, bn = b;
+            if (s + 1 < STEPS) {
+                an = *reinterpret_cast<const f32x4 *>(ca + 128 * (s + 1));
+                bn = *reinterpret_cast<const f32x4 *>(cb + 128 * (s + 1));
+            }
+            if (s < ISSUE_STEPS) {
+#pragma unroll
+                for (int k = 0; k < PER_STEP; ++k)
+                    if (s * PER_STEP + k < NJ) issue(s * PER_STEP + k, sa, sb, nxt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 8; m < 16; ++m)
+                acc[m / 4][m % 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m / 4], b[m % 4], acc[m / 4][m % 4], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a = an; b = bn;
+        }
+        __syncthreads();
+        cur = BUF_BYTES - cur;
+    }
+    // accumulator (i, j) register r of lane l = dW row 4 (A row group 4 (l >> 4) + r of the set) + i, column 4 (l & 15) + j
+    constexpr int ROWS = WA * 64, COLS = 64;
+    float *slab = partial + T.part_off + (int64_t)(chunk * WP + wp) * (ROWS * (COLS + 1));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * (wa * 16 + 4 * kq + r) + i;
+            *reinterpret_cast<f32x4 *>(slab + row * COLS + 4 * (lane & 15)) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float sum = bsum2[i >> 1][i & 1];
+        sum += __shfl_xor(sum, 16, WAVE);                                  // the four point residues of the row group
+        sum += __shfl_xor(sum, 32, WAVE);
+        if (kq == 0) slab[ROWS * COLS + 4 * (wa * 16 + (lane & 15)) + i] = sum;
+    }
+}
+
 struct GradPtrs {
     float *p[N_PARAMS];            // NeRF: 24 tensors; the FiLM-SIREN field uses the first 22
 };

@@ -287,9 +287,9 @@ nerf_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__restr
     switch (T.kind) {
         // dw_core.h dw_task4g<IA, JB4, WA, WB, WP, NA_P, NB_P> on the x4 images of the fp32 forward / chain
         case 0: dw_task4g<4, 4, 2, 2, 1, 32, 32, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 256
-        case 1: dw_task4g<4, 4, 2, 1, 2, 32, 8, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;    // 256 x 63 (xyz embedding)
+        case 1: dw_task4g16<4, 1, 32, 8, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;           // 256 x 63 (xyz embedding)
         case 2: dw_task4g<4, 4, 1, 2, 2, 16, 32, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 128 x 256
-        case 3: dw_task4g<4, 4, 1, 1, 4, 16, 4, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;    // 128 x 27 (dir embedding)
+        case 3: dw_task4g16<2, 2, 16, 4, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;           // 128 x 27 (dir embedding)
         case 4: dw_task4g<1, 4, 1, 1, 4, 2, 16, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;    // rgb 3 x 128
         default: dw_task4g<1, 4, 1, 2, 2, 2, 32, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // sigma 1 x 256
     }
@@ -302,8 +302,8 @@ nerf_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__restr
 
 // slab = 32 JB rows x 32 KB columns per kind: fp32 plan (dw_task4g forms above) / split-bf16 plan ([row][point] tasks)
 static const int KIND_JB[6] = {8, 8, 4, 4, 1, 1};
-static const int KIND_KB[6] = {8, 4, 8, 4, 4, 8};
-static const int KIND_WP[6] = {1, 2, 2, 4, 4, 2};      // slabs per workgroup (point ranges of a tile handled by different waves)
+static const int KIND_KB[6] = {8, 2, 8, 2, 4, 8};
+static const int KIND_WP[6] = {1, 1, 2, 2, 4, 2};      // slabs per workgroup (point ranges of a tile handled by different waves)
 static const int KIND_KB_FAST[6] = {8, 2, 8, 1, 4, 8};
 
 static DwPlan make_plan(int64_t ld, bool fast = false) {
@@ -327,12 +327,13 @@ static DwPlan make_plan(int64_t ld, bool fast = false) {
     add(5, fast ? W_DSIG : W_DSIG4, 1, S_H + 256 * 7, 256, PARAM_SIGMA_W, 0, 256, PARAM_SIGMA_B);     // sigma
     P.n_tasks = n;
     // chunks proportional to the measured cost of a task (per-workgroup shader-clock stamps, tools/exp_dw_timing.py ... fp32:
-    // 71.8 / 36.6 / 37.0 / 18.5 / 8.9 / 12.4 M cycles per task of kinds 0..5 at 4096 tiles), so that every workgroup costs the
-    // same and the grid is exactly 256 (one per CU: the LDS tiles of a workgroup fill a CU, so the kernel takes one workgroup's
-    // time, and leaving CUs without a chunk costs their share outright): 8 x 25 + 2 x 13 + 13 + 8 + 4 + 5 = 256.
-    // The embedding tasks (kind 1, 3) fill only half / a quarter of their 32 B lanes and the two heads are bound by the
-    // latency of their tile loads, not by their 16-32 MFMAs per tile: together 10 % of the kernel is spent there.
-    static const int base_fp32[6] = {25, 13, 13, 8, 4, 5};
+    // 71.7 / 21.3 / 36.9 / 12.6 / 9.1 / 12.5 M cycles per task of kinds 0..5 at 4096 tiles), so that every workgroup costs about
+    // the same and the grid is exactly 256 (one per CU: the LDS tiles of a workgroup fill a CU, so the kernel takes one
+    // workgroup's time, and leaving CUs without a chunk costs their share outright): 8 x 26 + 2 x 9 + 14 + 6 + 4 + 6 = 256.
+    // The 256 x 256 tasks set the time (2.76 M cycles per workgroup, 93 % of it MFMAs); the two heads are bound by the latency
+    // of their tile loads, not by their 16-32 MFMAs per tile.  (With the embedding tasks in the 32-lane form, half / a quarter of
+    // whose B lanes are empty, those cost 36.6 / 18.5 M cycles and the best split was 8 x 25 + ...: kernel +4 %.)
+    static const int base_fp32[6] = {26, 9, 14, 6, 4, 6};
     // split-bf16 variant: the 256 x 256 tasks run ~2x faster per tile, so the fp32 tasks get the larger share of CUs:
     // 8 x 24 + 2 x 12 + 18 + 6 + 6 + 10 = 256, from measured per-task workgroup times (tools/exp_dw_timing.py:
     // 38.2 / 18.5 / 25.5 / 8.4 / 8.5 / 12.6 M cycles per task at 4096 tiles); the tiny tasks 3..5 stay on the fp32 path
