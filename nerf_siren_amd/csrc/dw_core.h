@@ -188,9 +188,8 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
 // operand whose few rows sit in unit 0 of their own row groups; WP = point ranges of a tile handled by different waves, each
 // writing its own slab: the reduction sums slabs anyway; NA_P / NB_P = 1 KiB pieces (8 rows) that really exist and are staged,
 // the lanes past them multiply whatever the LDS holds into rows / columns the reduction drops):
-//   FiLM-SIREN  256 x 256 <4,4,2,2,1,32,32>   256 x 3 (x, y, z / direction) <4,1,2,1,2,32,2>   heads 3 x 256 <1,4,1,2,2,2,32>
-//   NeRF        256 x 256 <4,4,2,2,1,32,32>   256 x 63 (embedding) <4,4,2,1,2,32,8>   128 x 256 <4,4,1,2,2,16,32>
-//               128 x 27 (direction embedding) <4,4,1,1,4,16,4>   rgb 3 x 128 <1,4,1,1,4,2,16>   sigma 1 x 256 <1,4,1,2,2,2,32>
+//   in use: 256 x 256 <4,4,2,2,1,32,32> (both fields), NeRF 128 x 256 <4,4,1,2,2,16,32>; the tasks with a small operand run
+//   the 16-lane form below (dw_task4g16), where their operand sets are full
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) void gbl_void_t;
@@ -326,28 +325,41 @@ __device__ __forceinline__ void dw_task4g(const DwTask &T, int chunk, const floa
     }
 }
 
-// The same GEMM for a B operand of at most 64 rows (the NeRF embeddings: 63 / 27 columns of dW), on v_mfma_f32_16x16x4_f32:
-// in the 32-lane form above such an operand fills half (a quarter) of the 32 B lanes and every MFMA wastes that share of
-// its work.  Here a wave's A set and the B set are 16 row groups each: lane l reads the 16-byte word (row group l & 15, point
-// 4 s + (l >> 4)), unit i of it is operand A_i / B_j of a 16 x 16 x 4 MFMA (same FLOP per cycle as 32 x 32 x 2), the 4 x 4 products
-// fill a 64 x 64 tile of dW, a step covers four points, a tile eight steps.  Waves: WA A sets (64 rows each) x WP point
-// ranges; same staging, same slab format.   256 x 63 <4, 1, 32, 8>   128 x 27 <2, 2, 16, 4>
-template <int WA, int WP, int NA_P, int NB_P, int AROWS, int BROWS>
+// The same GEMM on v_mfma_f32_16x16x4_f32 for tasks with a SMALL operand (the NeRF embeddings: 63 / 27 columns of dW; the
+// K = 3 inputs and the heads of both fields): in the 32-lane form above an operand of <= 64 rows fills at most half of the 32
+// lanes and every MFMA wastes that share of its work.  Here an operand set is 16 row groups: lane l reads the 16-byte word
+// (row group l & 15, point 4 s + (l >> 4)), unit i of it is operand A_i / B_j of a 16 x 16 x 4 MFMA (same FLOP per cycle as
+// 32 x 32 x 2), a step covers four points, a tile eight steps.  IA / JB4 = 4: all four units (64 rows per set, WA / WB sets);
+// = 1: unit 0 only (a narrow operand: its rows in unit 0 of their own row groups).  Same staging, same slab format (slabs of
+// narrow operands are padded to 32 rows / columns).
+//   NeRF    256 x 63 <4,4,4,1,1,32,8,3>   128 x 27 <4,4,2,1,2,16,4,5>   rgb 3 x 128 <1,4,1,2,2,2,16,5>   sigma 1 x 256 <1,4,1,4,1,2,32,3>
+//   SIREN   256 x 3 <4,1,4,1,1,32,2,3>    heads 3 x 256 / 1 x 256 <1,4,1,4,1,2,32,3>
+template <int IA, int JB4, int WA, int WB, int WP, int NA_P, int NB_P, int NBUF, int AROWS, int BROWS>
 __device__ __forceinline__ void dw_task4g16(const DwTask &T, int chunk, const float *__restrict__ work,
                                             const float *__restrict__ saved, int64_t ld, float *__restrict__ partial,
                                             float *lds) {
-    static_assert(WA * WP == 4, "four waves per workgroup");
+    static_assert(WA * WB * WP == 4, "four waves per workgroup");
     constexpr int PIECE = 1056;
-    constexpr int A_AL = WA * 8, B_AL = 8;                // pieces of LDS per operand: 16 row groups per set
-    static_assert(NA_P <= A_AL && NB_P <= B_AL && NA_P >= NB_P && NA_P % 4 == 0 && NB_P % 4 == 0, "piece counts");
+    constexpr int A_AL = (IA == 4) ? WA * 8 : 8, B_AL = (JB4 == 4) ? WB * 8 : 8;   // pieces of LDS per operand: 16 row groups per set
+    static_assert(NA_P <= A_AL && NB_P <= B_AL, "staged pieces fit their region");
     constexpr int BUF_BYTES = (A_AL + B_AL) * PIECE;
-    constexpr int NJ = (NA_P + NB_P) / 4;                 // pieces per tile per wave: the A pieces, then the B pieces
+    // These tasks have 32-128 MFMAs (1-4 k cycles) per tile: with the next tile's pieces issued only ONE tile ahead, a tile took
+    // the latency of its loads (2.8 k cycles per tile measured, whatever the MFMA count).  So NBUF LDS buffers, the pieces of
+    // tile t + NBUF - 1 issued during tile t, and at the top of a tile a COUNTED wait -- the newest (NBUF - 2) tiles' pieces may
+    // stay in flight -- in front of a raw s_barrier (__syncthreads() would drain every LDS-DMA in flight with vmcnt(0)).
+    static_assert(NBUF >= 2 && NBUF * BUF_BYTES <= 147456, "the ring fits the workgroup's dynamic LDS");
+    constexpr int AHEAD = NBUF - 1;
+    constexpr bool A_FIRST = NA_P >= NB_P;                // piece order of a tile: the wide operand first
+    constexpr int NF = A_FIRST ? NA_P : NB_P;
+    static_assert(NF % 4 == 0, "the wide operand's pieces fill whole rounds");
+    constexpr int NP = NA_P + NB_P, NJ = (NP + 3) / 4;    // pieces per tile, per wave
     constexpr int STEPS = 8 / WP;
     constexpr int ISSUE_STEPS = STEPS / 2;
     constexpr int PER_STEP = (NJ + ISSUE_STEPS - 1) / ISSUE_STEPS;
+    constexpr int NM = IA * JB4;                          // MFMAs per step
     const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wa = wid % WA, wp = wid / WA;
+    const int wa = wid % WA, wb = (wid / WA) % WB, wp = wid / (WA * WB);
     const int wg_chunks = T.chunks / WP;
     const int64_t tiles = ld / 32;
     const int64_t t_lo = tiles * chunk / wg_chunks, t_hi = tiles * (chunk + 1) / wg_chunks;
@@ -356,41 +368,59 @@ __device__ __forceinline__ void dw_task4g16(const DwTask &T, int chunk, const fl
     char *lbase = reinterpret_cast<char *>(lds);
     const unsigned poff = (unsigned)((lane & 1) * 512 + (lane >> 1) * 16);
     auto issue = [&](int j, const char *sa, const char *sb, char *buf) __attribute__((always_inline)) {
-        const bool is_a = j < NA_P / 4;                   // compile-time after unrolling
-        const int p = is_a ? 4 * j + wid : 4 * (j - NA_P / 4) + wid;
+        const bool first = j < NF / 4;                    // compile-time after unrolling
+        int p = first ? 4 * j + wid : 4 * (j - NF / 4) + wid;
+        // a ragged last round re-fetches the operand's last piece (same bytes to the same place): every wave issues NJ pieces
+        // per tile, which is what the counted wait below counts
+        if ((NP - NF) % 4 != 0 && !first && p >= NP - NF) p = NP - NF - 1;
+        const bool is_a = first == A_FIRST;
         const char *src = (is_a ? sa : sb) + p * 1024;
         char *dst = buf + (is_a ? 0 : A_AL * PIECE) + p * PIECE;
         __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + poff), (lds_void_t *)dst, 16, 0, 0);
     };
-    f32x4 acc[4][4];
+    f32x4 acc[IA][JB4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < IA; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < JB4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x2 bsum2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+    static_assert((AHEAD - 1) * NJ <= 63, "vmcnt is a 6-bit counter");
     if (t_lo < t_hi) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) issue(j, abase + t_lo * (int64_t)(AROWS * 128), bbase + t_lo * (int64_t)(BROWS * 128), lbase);
+        for (int d = 0; d < AHEAD; ++d) {
+            const int64_t td = (t_lo + d < t_hi) ? t_lo + d : t_hi - 1;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                issue(j, abase + td * (int64_t)(AROWS * 128), bbase + td * (int64_t)(BROWS * 128), lbase + d * BUF_BYTES);
+        }
     }
-    __syncthreads();
     // (row group g, point 4 s + kq) at piece (g >> 1), slot 2 (4 s + kq) + (g & 1): 128 bytes per step
-    const int rga = wa * 16 + (lane & 15), rgb = lane & 15;
+    const int rga = ((IA == 4) ? wa * 16 : 0) + (lane & 15), rgb = ((JB4 == 4) ? wb * 16 : 0) + (lane & 15);
     const unsigned a_off = (unsigned)((rga >> 1) * PIECE + (rga & 1) * 16 + kq * 32 + STEPS * wp * 128);
     const unsigned b_off = (unsigned)(A_AL * PIECE + (rgb >> 1) * PIECE + (rgb & 1) * 16 + kq * 32 + STEPS * wp * 128);
-    int cur = 0;
+    int cur = 0;                                          // byte offset of the buffer being consumed
     for (int64_t t = t_lo; t < t_hi; ++t) {
-        const int64_t t1 = (t + 1 < t_hi) ? t + 1 : t_hi - 1;
+        // tile t's pieces (issued AHEAD tiles ago, by every wave) have landed; everybody is done with the buffer of tile t - 1,
+        // which is the one tile t + AHEAD goes to
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * NJ) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int64_t t1 = (t + AHEAD < t_hi) ? t + AHEAD : t_hi - 1;   // past the end: restage the last tile (branch-free)
         const char *sa = abase + t1 * (int64_t)(AROWS * 128), *sb = bbase + t1 * (int64_t)(BROWS * 128);
         const char *ca = lbase + cur + a_off, *cb = lbase + cur + b_off;
-        char *nxt = lbase + (BUF_BYTES - cur);
+        char *nxt = lbase + (cur == 0 ? (NBUF - 1) * BUF_BYTES : cur - BUF_BYTES);
         f32x4 a = *reinterpret_cast<const f32x4 *>(ca), b = *reinterpret_cast<const f32x4 *>(cb);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
-            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(bsum2[0]) : "v"(f32x2{a[0], a[1]}));
-            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(bsum2[1]) : "v"(f32x2{a[2], a[3]}));
+            if (IA == 4) {
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(bsum2[0]) : "v"(f32x2{a[0], a[1]}));
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(bsum2[1]) : "v"(f32x2{a[2], a[3]}));
+            } else {
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum2[0][0]) : "v"(a[0]));
+            }
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
-                acc[m / 4][m % 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m / 4], b[m % 4], acc[m / 4][m % 4], 0, 0, 0);
+            for (int m = 0; m < NM / 2; ++m)
+                acc[m / JB4][m % JB4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m / JB4], b[m % JB4], acc[m / JB4][m % JB4], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 an = a, bn = b;
             if (s + 1 < STEPS) {
@@ -404,30 +434,39 @@ __device__ __forceinline__ void dw_task4g16(const DwTask &T, int chunk, const fl
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 8; m < 16; ++m)
-                acc[m / 4][m % 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m / 4], b[m % 4], acc[m / 4][m % 4], 0, 0, 0);
+            for (int m = NM / 2; m < NM; ++m)
+                acc[m / JB4][m % JB4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m / JB4], b[m % JB4], acc[m / JB4][m % JB4], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             a = an; b = bn;
         }
-        __syncthreads();
-        cur = BUF_BYTES - cur;
+        cur = (cur == (NBUF - 1) * BUF_BYTES) ? 0 : cur + BUF_BYTES;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the restaged pieces past the end: nothing in flight when the wave ends)
     // accumulator (i, j) register r of lane l = dW row 4 (A row group 4 (l >> 4) + r of the set) + i, column 4 (l & 15) + j
-    constexpr int ROWS = WA * 64, COLS = 64;
+    constexpr int ROWS = (IA == 4) ? WA * 64 : 32, COLS = (JB4 == 4) ? WB * 64 : 32;   // (narrow: 16 real, padded to a block)
     float *slab = partial + T.part_off + (int64_t)(chunk * WP + wp) * (ROWS * (COLS + 1));
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < IA; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = 4 * (wa * 16 + 4 * kq + r) + i;
-            *reinterpret_cast<f32x4 *>(slab + row * COLS + 4 * (lane & 15)) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+            const int m = 4 * kq + r;
+            const int row = (IA == 4) ? 4 * (wa * 16 + m) + i : m;
+            if (JB4 == 4) {
+                const int col = 4 * (wb * 16 + (lane & 15));
+                *reinterpret_cast<f32x4 *>(slab + row * COLS + col) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+            } else {
+                slab[row * COLS + (lane & 15)] = acc[i][0][r];
+            }
         }
+    if (wb == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float sum = bsum2[i >> 1][i & 1];
-        sum += __shfl_xor(sum, 16, WAVE);                                  // the four point residues of the row group
-        sum += __shfl_xor(sum, 32, WAVE);
-        if (kq == 0) slab[ROWS * COLS + 4 * (wa * 16 + (lane & 15)) + i] = sum;
+        for (int i = 0; i < IA; ++i) {
+            float sum = bsum2[i >> 1][i & 1];
+            sum += __shfl_xor(sum, 16, WAVE);                              // the four point residues of the row group
+            sum += __shfl_xor(sum, 32, WAVE);
+            const int row = (IA == 4) ? 4 * (wa * 16 + (lane & 15)) + i : (lane & 15);
+            if (kq == 0) slab[ROWS * COLS + row] = sum;
+        }
     }
 }
 

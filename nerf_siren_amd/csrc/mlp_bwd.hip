@@ -285,13 +285,13 @@ nerf_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__restr
     const DwTask T = plan.t[ti];
     const int chunk = blockIdx.x - T.wg0;
     switch (T.kind) {
-        // dw_core.h dw_task4g<IA, JB4, WA, WB, WP, NA_P, NB_P> on the x4 images of the fp32 forward / chain
+        // dw_core.h dw_task4g<IA, JB4, WA, WB, WP, NA_P, NB_P> / dw_task4g16<..., NBUF> on the x4 images of the fp32 forward / chain
         case 0: dw_task4g<4, 4, 2, 2, 1, 32, 32, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 256
-        case 1: dw_task4g16<4, 1, 32, 8, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;           // 256 x 63 (xyz embedding)
+        case 1: dw_task4g16<4, 4, 4, 1, 1, 32, 8, 3, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;  // 256 x 63 (xyz embedding)
         case 2: dw_task4g<4, 4, 1, 2, 2, 16, 32, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 128 x 256
-        case 3: dw_task4g16<2, 2, 16, 4, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;           // 128 x 27 (dir embedding)
-        case 4: dw_task4g<1, 4, 1, 1, 4, 2, 16, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;    // rgb 3 x 128
-        default: dw_task4g<1, 4, 1, 2, 2, 2, 32, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // sigma 1 x 256
+        case 3: dw_task4g16<4, 4, 2, 1, 2, 16, 4, 5, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;  // 128 x 27 (dir embedding)
+        case 4: dw_task4g16<1, 4, 1, 2, 2, 2, 16, 5, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;  // rgb 3 x 128
+        default: dw_task4g16<1, 4, 1, 4, 1, 2, 32, 3, W_ROWS, SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break; // sigma 1 x 256
     }
 #ifdef NERFMI_TIMING
     if (threadIdx.x == 0) nerfmi_dbg_dw[blockIdx.x] = __builtin_readcyclecounter() - t_start;
@@ -303,7 +303,7 @@ nerf_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__restr
 // slab = 32 JB rows x 32 KB columns per kind: fp32 plan (dw_task4g forms above) / split-bf16 plan ([row][point] tasks)
 static const int KIND_JB[6] = {8, 8, 4, 4, 1, 1};
 static const int KIND_KB[6] = {8, 2, 8, 2, 4, 8};
-static const int KIND_WP[6] = {1, 1, 2, 2, 4, 2};      // slabs per workgroup (point ranges of a tile handled by different waves)
+static const int KIND_WP[6] = {1, 1, 2, 2, 2, 1};      // slabs per workgroup (point ranges of a tile handled by different waves)
 static const int KIND_KB_FAST[6] = {8, 2, 8, 1, 4, 8};
 
 static DwPlan make_plan(int64_t ld, bool fast = false) {

@@ -297,8 +297,9 @@ siren_dw_kernel(DwPlan plan, const float *__restrict__ work, const float *__rest
     switch (T.kind) {
         // dw_core.h dw_task4g<IA, JB4, WA, WB, WP>
         case 0: dw_task4g<4, 4, 2, 2, 1, 32, 32, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 256
-        case 1: dw_task4g<4, 1, 2, 1, 2, 32, 2, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 3 (x, y, z / direction)
-        default: dw_task4g<1, 4, 1, 2, 2, 2, 32, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;  // 3 x 256 (heads)
+        // the narrow tasks on the 16 x 16 x 4 MFMA (dw_task4g16: 16 row groups per operand set)
+        case 1: dw_task4g16<4, 1, 4, 1, 1, 32, 2, 3, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;   // 256 x 3 (x, y, z / direction)
+        default: dw_task4g16<1, 4, 1, 4, 1, 2, 32, 3, SW_ROWS, SIREN_SAVED_ROWS>(T, chunk, work, saved, ld, partial, lds); break;  // 3 x 256 (heads)
     }
 #ifdef NERFMI_TIMING
     if (threadIdx.x == 0) nerfmi_dbg_siren_dw[blockIdx.x] = __builtin_readcyclecounter() - t_start;
@@ -401,8 +402,7 @@ static DwPlan siren_plan(int64_t ld, bool fast = false) {
         DwTask &t = P.t[n++];
         t.kind = kind; t.a_row0 = a_row0; t.a_valid = a_valid; t.b_row0 = b_row0; t.b_valid = b_valid;
         t.param = param; t.out_col0 = col0; t.in_f = in_f; t.bias_param = bias;
-        // fp32 path (dw_task4g): the narrow tasks split a tile's points over two wave pairs = two slabs per workgroup
-        t.wp = (!fast && kind != 0) ? 2 : 1;
+        t.wp = 1;                                       // one slab per workgroup in every form this plan uses
     };
     // B rows past b_valid are whatever follows in the tile (the GEMM's extra columns are dropped by the reduction)
     add(1, SW_DZ, 256, SS_X, 3, 0, 0, 3, 1);                                                    // network.0: X = warped xyz
@@ -412,10 +412,11 @@ static DwPlan siren_plan(int64_t ld, bool fast = false) {
     add(2, SW_DRGB, 3, SS_HC, 256, 20, 0, 256, 21);                                             // color_layer_linear.0
     add(2, fast ? SW_DSIG : SW_DSIG4, 1, SS_H + 256 * 7, 256, 16, 0, 256, 17);                  // final_layer
     P.n_tasks = n;
-    // 8 x 29 + 2 x 6 + 2 x 6 = 256 workgroups, one per CU (shares from per-task workgroup stamps, tools/exp_siren_dw_timing.py).
-    // The two K = 3 tasks (network.0: X = xyz; colour layer: dir columns) use the narrowest B tile there is, 32 columns:
-    // as 64-column tasks they kept 20 workgroups busy multiplying zero padding.
-    static const int chunks_default[3] = {29, 6, 6};
+    // 8 x 30 + 2 x 4 + 2 x 4 = 256 workgroups, one per CU (shares from per-task workgroup stamps, tools/exp_siren_dw_timing.py:
+    // 71.6 / 7.5 / 8.4 M cycles per task of kinds 0..2 at 4096 tiles; {29,6,6}, {30,5,3}, {30,3,5} measured slower).  The four
+    // narrow tasks cost 11.4-12.1 M cycles each while a tile of theirs took the latency of its loads; with the three-buffer ring
+    // of dw_task4g16 they fit into 16 workgroups instead of 24.
+    static const int chunks_default[3] = {30, 4, 4};
     // split-bf16 variant: the 256 x 256 tasks run ~2x faster per tile, so the fp32 narrow tasks get the larger share of CUs:
     // 8 x 24 + 2 x 16 + 2 x 16 = 256
     static const int chunks_fast[3] = {24, 16, 16};
