@@ -674,6 +674,30 @@ def _rel(a, b):
     return float(np.linalg.norm((a - b).astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
 
 
+def test_saved_images_belong_to_the_math_that_wrote_them(ops, dev, models, siren):
+    """The fp32 and the split-bf16 training paths order the elements of a 32-point tile of the saved-activation image differently
+    (csrc/siren_core.h, mlp_layout.h): handing an image to the backward of the other math must raise, not compute garbage."""
+    params, ms = models
+    rays = T(synth.blender_rays(4, 61), dev)
+    z = T(np.sort(synth.hash_uniform((4, 16), 62) * 4 + 2, -1).astype(np.float32), dev)
+    g = T(synth.hash_normal((64, 4), 63), dev)
+    _, saved32 = ops.nerf_forward_rays(ms[0].packed(), rays, z, save=True)
+    _, saved16 = ops.nerf_forward_rays_fast(ms[0].packed(), ms[0].packed_fast(), rays, z, save=True)
+    with pytest.raises(ValueError, match="same math"):
+        ops.nerf_backward_rays(ms[0].packed(), rays, z, saved32, g, fast=ms[0].packed_fast())
+    with pytest.raises(ValueError, match="same math"):
+        ops.nerf_backward_rays(ms[0].packed(), rays, z, saved16, g)
+    m = siren[1] if isinstance(siren, (tuple, list)) else siren
+    sm = m.model if hasattr(m, "model") else m
+    fr, ph = torch.randn(1, 2304, device=dev), torch.randn(1, 2304, device=dev)
+    _, s32 = ops.siren_forward_rays_train(sm.packed(), rays, z, fr, ph, 4)
+    _, s16 = ops.siren_forward_rays_train(sm.packed(), rays, z, fr, ph, 4, fast=sm.packed_fast())
+    with pytest.raises(ValueError, match="same math"):
+        ops.siren_backward(sm.packed(), s32, g, fr, 64, fast=sm.packed_fast())
+    with pytest.raises(ValueError, match="same math"):
+        ops.siren_backward(sm.packed(), s16, g, fr, 64)
+
+
 def test_siren_backward_vs_reference_autograd(golden, dev, siren):
     """Gradients of all 22 parameters through SemanticNeRF.forward_with_frequencies_phase_shifts against the
     REFERENCE's autograd (fixture g8b, tools/make_golden.py:g_siren) and the oracle's manual backward.  Three
