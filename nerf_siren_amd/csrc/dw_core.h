@@ -191,9 +191,6 @@ __device__ __forceinline__ void dw_task(const DwTask &T, int chunk, const float 
 //   in use: 256 x 256 <4,4,2,2,1,32,32> (both fields), NeRF 128 x 256 <4,4,1,2,2,16,32>; the tasks with a small operand run
 //   the 16-lane form below (dw_task4g16), where their operand sets are full
 // ---------------------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) void gbl_void_t;
-
 template <int IA, int JB4, int WA, int WB, int WP, int NA_P, int NB_P, int AROWS, int BROWS>
 __device__ __forceinline__ void dw_task4g(const DwTask &T, int chunk, const float *__restrict__ work,
                                           const float *__restrict__ saved, int64_t ld, float *__restrict__ partial,

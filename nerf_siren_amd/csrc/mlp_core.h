@@ -110,6 +110,9 @@ constexpr int NSLOT = 4;
 constexpr int WLDS_FLOATS = NSLOT * GS * 256;   // 64 KiB
 constexpr int QS = GS / 4;                 // fragments per wave per stage
 
+typedef __attribute__((address_space(3))) void lds_void_t;    // operands of __builtin_amdgcn_global_load_lds
+typedef __attribute__((address_space(1))) void gbl_void_t;
+
 template <int GS_>
 struct WeightStageT {
     f32x4 st[GS_ / 4];                     // this wave's quarter of the stage in flight
@@ -119,8 +122,18 @@ using WeightStage = WeightStageT<GS>;
 template <int KB0, int KB1, int JB>
 constexpr int layer_stages() { return JB * (KB0 + KB1) * 4 / GS; }
 
-// GS_: fragments per stage of THIS kernel's ring (the FiLM-SIREN kernels run longer stages: siren_core.h SIREN_GS)
-template <int KB0, int KB1, int JB, int PH, bool FIRST, int GS_ = GS, class Pre, class Epi>
+// GS_: fragments per stage of THIS kernel's ring (siren_core.h SIREN_GS).
+// DMA (all layers of a kernel alike): the stream goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: a wave's fragment is
+// 64 lanes x 16 B = the 1 KiB the readers expect, no staging registers, no ds_write): during stage s a wave issues its quarter
+// of stage s+2 straight into ring slot (s+2) % 4 -- free since the barrier in the middle of stage s-1, when every wave had left
+// stage s-2 --, and the barrier in the middle of stage s+1 publishes it behind a COUNTED wait: everything but the newest QS
+// vector-memory operations (stage s+3's pieces, issued a few groups earlier) must have landed, which covers stage s+2's
+// pieces whatever stores the epilogues put into the queue since.  A raw s_barrier: __syncthreads() would drain the queue.
+// A kernel that uses it ends with ring_drain(): an LDS-DMA still in flight when the workgroup's LDS is handed on would write
+// into the next workgroup's.
+__device__ __forceinline__ void ring_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int KB0, int KB1, int JB, int PH, bool FIRST, int GS_ = GS, bool DMA = false, class Pre, class Epi>
 __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, const float *__restrict__ bias,
                                                const f32x16 *in0, const f32x16 *in1, f32x16 *out, Pre pre, Epi epi,
                                                float *wlds, WeightStageT<GS_> &ws, int wid, int lane) {
@@ -144,12 +157,28 @@ __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, 
     auto lread = [&](int g) {
         return *reinterpret_cast<const f32x4 *>(lsrc + (((g / GS_ + PH) % NSLOT) * GS_ + g % GS_) * 256);
     };
+    const int swid = __builtin_amdgcn_readfirstlane(wid);           // (scalar: the DMA's LDS base goes through M0)
+    auto dma = [&](int stage, int i) __attribute__((always_inline)) {   // fragment QS_ * wave + i of `stage` into its ring slot
+        const float *src = wbase + (stage * GS_ + QS_ * swid + i) * 256 + lane * 4;
+        float *dst = wlds + (((stage + PH) % NSLOT) * GS_ + QS_ * swid + i) * 256;
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)dst, 16, 0, 0);
+    };
     if (FIRST) {
         __syncthreads();
-        gload(0);
-        lwrite(0);
-        gload(1);
-        __syncthreads();
+        if (DMA) {
+#pragma unroll
+            for (int i = 0; i < QS_; ++i) dma(0, i);
+#pragma unroll
+            for (int i = 0; i < QS_; ++i) dma(1, i);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            gload(0);
+            lwrite(0);
+            gload(1);
+            __syncthreads();
+        }
     }
     f32x16 c_prev;
     f32x4 a_next;
@@ -188,11 +217,23 @@ __device__ __forceinline__ void layer_mfma_lds(const float *__restrict__ wbase, 
                 // the four 1 KiB LDS writes (and loads) of all four waves queue on the LDS/TA pipes and the wave
                 // waits; one per MFMA group is absorbed (tools/ubench/mfma_valu.hip).
                 if (gl < QS_) {
-                    *reinterpret_cast<f32x4 *>(ldst + (((stage + 1 + PH) % NSLOT) * GS_ + gl) * 256) = ws.st[gl];
-                    ws.st[gl] = ldg4(gsrc + ((stage + 2) * GS_ + gl) * 256);
+                    if (DMA) {
+                        dma(stage + 2, gl);
+                    } else {
+                        *reinterpret_cast<f32x4 *>(ldst + (((stage + 1 + PH) % NSLOT) * GS_ + gl) * 256) = ws.st[gl];
+                        ws.st[gl] = ldg4(gsrc + ((stage + 2) * GS_ + gl) * 256);
+                    }
                 }
 #ifndef NERFMI_EXP_NOBARRIER
-                if (gl == GS_ / 2) __syncthreads();
+                if (gl == GS_ / 2) {
+                    if (DMA) {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QS_) : "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    } else {
+                        __syncthreads();
+                    }
+                }
 #endif
                 // fragments are read ONE group ahead (two register sets): the LDS latency of group g+1 hides
                 // behind group g's four MFMAs instead of draining the pipe in front of every group

@@ -139,7 +139,7 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
     const int wid = threadIdx.x >> 6;
     WeightStageT<SIREN_GS> ws;
     // d h_7 = W_c[:, 3:]^T dZ_c + w_sigma d sigma;  dZ_7 = d h_7 * fr_7 * cos(arg_7)      (nerf.py:212-213)
-    layer_mfma_lds<8, 0, 8, 0, true, SIREN_GS>(packed + SOFF_TCOLOR, nullptr, dzA, nullptr, dzB,
+    layer_mfma_lds<8, 0, 8, 0, true, SIREN_GS, SIREN_DMA>(packed + SOFF_TCOLOR, nullptr, dzA, nullptr, dzB,
                                      [&S](int jb) { return load_cos_block(S, 7, jb); },
                                      [&](int jb, int q, f32x4 c, const f32x16 &sv) {
                                          const f32x4 w = ldg4(packed + SOFF_W_SIGMA + 32 * jb + 8 * q + 4 * half);
@@ -152,7 +152,7 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
                                      }, wlds, ws, wid, lane);
     // network.7 .. network.1: d h_{l-1} = W_l^T dZ_l;  dZ_{l-1} = d h_{l-1} * fr_{l-1} * cos(arg_{l-1})
     auto back = [&](int l, const f32x16 *in, f32x16 *out_dz) __attribute__((always_inline)) {
-        layer_mfma_lds<8, 0, 8, 0, false, SIREN_GS>(packed + SOFF_T7 + (7 - l) * SZ_HID, nullptr, in, nullptr, out_dz,
+        layer_mfma_lds<8, 0, 8, 0, false, SIREN_GS, SIREN_DMA>(packed + SOFF_T7 + (7 - l) * SZ_HID, nullptr, in, nullptr, out_dz,
                                           [&S, l](int jb) { return load_cos_block(S, l - 1, jb); },
                                           [&, l](int jb, int q, f32x4 c, const f32x16 &sv) {
                                               f32x4 g;
@@ -168,6 +168,7 @@ siren_backward_chain_kernel(const float *__restrict__ packed, const float *__res
     back(3, dzB, dzA);
     back(2, dzA, dzB);
     back(1, dzB, dzA);
+    if (SIREN_DMA) ring_drain();
 }
 
 // ---------------------------------------------------------------------------

@@ -37,6 +37,12 @@ constexpr int SOFF_T7 = SOFF_TCOLOR + SZ_HID;       // network.l at SOFF_T7 + (7
 #define NERFMI_SIREN_GS 16
 #endif
 constexpr int SIREN_GS = NERFMI_SIREN_GS;
+#ifndef NERFMI_SIREN_DMA
+#define NERFMI_SIREN_DMA 0
+#endif
+// the weight ring by LDS-DMA (mlp_core.h layer_mfma_lds<..., DMA>): measured slower (forward-with-save +0.9 %, chain +4.9 %,
+// inference +1.4 %; with 32-fragment stages +3.0 % / +13.4 % / +4.7 %), kept as an experiment switch
+constexpr bool SIREN_DMA = NERFMI_SIREN_DMA != 0;
 constexpr int SIREN_PH = (32 / SIREN_GS) % NSLOT;      // ring phase behind network.0 (32 fragments); the hidden layers keep it
 constexpr int SIREN_WLDS_BYTES = NSLOT * SIREN_GS * 1024;
 constexpr int SIREN_STREAM_TAIL = 2 * SIREN_GS * 256;
@@ -212,9 +218,9 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
     f32x16 hA[8], hB[8];                   // alternate: a layer reads one, its epilogue writes the other (no copies)
     WeightStageT<SIREN_GS> ws;
     // ring phases: network.0 is 32 fragments, every hidden layer a multiple of four stages: the hidden and color layers start at SIREN_PH
-    layer_mfma_lds<1, 0, 8, 0, true, SIREN_GS>(packed + SOFF_L1, bias, e, nullptr, hA, no_pre, film_epi(0), wlds, ws, wid, lane);
+    layer_mfma_lds<1, 0, 8, 0, true, SIREN_GS, SIREN_DMA>(packed + SOFF_L1, bias, e, nullptr, hA, no_pre, film_epi(0), wlds, ws, wid, lane);
     auto hidden = [&](int l, const f32x16 *in, f32x16 *out_h) __attribute__((always_inline)) {
-        layer_mfma_lds<8, 0, 8, SIREN_PH, false, SIREN_GS>(packed + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, in, nullptr, out_h, no_pre,
+        layer_mfma_lds<8, 0, 8, SIREN_PH, false, SIREN_GS, SIREN_DMA>(packed + SOFF_L2 + (l - 1) * SZ_HID, bias + 256 * l, in, nullptr, out_h, no_pre,
                                           film_epi(l), wlds, ws, wid, lane);
     };
     hidden(1, hA, hB);
@@ -227,9 +233,10 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
     const float sigma = dot_blocks<8>(hB, packed + SOFF_W_SIGMA + 4 * half) + packed[SOFF_B_SIGMA];   // nerf.py:212
     if (SIGMA_ONLY) {
         if (ok && half == 0) out[p] = sigma;
+        if (SIREN_DMA) ring_drain();
         return;
     }
-    layer_mfma_lds<1, 8, 8, SIREN_PH, false, SIREN_GS>(packed + SOFF_COLOR, bias + 256 * 8, de, hB, hA, no_pre, film_epi(8), wlds, ws, wid, lane);            // nerf.py:213
+    layer_mfma_lds<1, 8, 8, SIREN_PH, false, SIREN_GS, SIREN_DMA>(packed + SOFF_COLOR, bias + 256 * 8, de, hB, hA, no_pre, film_epi(8), wlds, ws, wid, lane);            // nerf.py:213
     float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -246,6 +253,7 @@ siren_forward_kernel(const float *__restrict__ packed, const float *__restrict__
         *S.at(SS_RGB + 1) = ok ? rgb[1] : 0.f;
         *S.at(SS_RGB + 2) = ok ? rgb[2] : 0.f;
     }
+    if (SIREN_DMA) ring_drain();
 }
 
 static inline int64_t siren_pad_points(int64_t n) { return (n + 31) / 32 * 32; }
