@@ -55,12 +55,20 @@ class _RenderFn(torch.autograd.Function):
         wb = opts.get('white_back', False)
         planes_hwc = ren._pack(planes)
         dec = decoder.packed()
+        # density_noise (renderer.py:149-150): sigma += randn_like(sigma) * density_noise behind both run_model calls -- additive,
+        # so the backward is unchanged (d sigma passes through); opts['rng_density_noise'] = (coarse, fine) injects the draws
+        dn = float(opts.get('density_noise', 0) or 0)
+        inj = opts.get('rng_density_noise')
         colors_c, dens_c = eg3d_ops.run_model_rays(planes_hwc, N, dec, ray_o, ray_d, depths_coarse, opts['box_warp'])
+        if dn > 0:
+            dens_c = dens_c + (torch.randn_like(dens_c) if inj is None else inj[0].reshape(dens_c.shape).to(dens_c)) * dn
         cc, sc = colors_c.reshape(N * M, S, 3), dens_c.reshape(N * M, S)
         mm_c = eg3d_ops.minmax(depths_coarse)
         rgb_c, depth_c, w_c, wsum_c = eg3d_ops.march(cc, sc, depths_coarse, wb, mm_c)
         depths_fine = eg3d_ops.sample_importance(depths_coarse, w_c, u, F)
         colors_f, dens_f = eg3d_ops.run_model_rays(planes_hwc, N, dec, ray_o, ray_d, depths_fine, opts['box_warp'])
+        if dn > 0:
+            dens_f = dens_f + (torch.randn_like(dens_f) if inj is None else inj[1].reshape(dens_f.shape).to(dens_f)) * dn
         cf, sf = colors_f.reshape(N * M, F, 3), dens_f.reshape(N * M, F)
         all_d, all_c, all_s, idx = eg3d_ops.unify(depths_coarse, cc, sc, depths_fine, cf, sf, want_idx=True)
         mm_f = eg3d_ops.minmax(all_d)
@@ -143,8 +151,6 @@ class ImportanceRenderer(torch.nn.Module):
                                                        opts.get('disparity_space_sampling', False), device=dev)
         o, d = ray_origins.detach().contiguous(), ray_directions.detach().contiguous()
         if train:
-            if opts.get('density_noise', 0) > 0:
-                raise NotImplementedError("density_noise is not supported in training mode")
             F_ = opts['depth_resolution_importance']
             if F_ <= 0:
                 raise ValueError(_NO_IMPORTANCE)
@@ -158,8 +164,10 @@ class ImportanceRenderer(torch.nn.Module):
         wb = opts.get('white_back', False)
 
         colors_coarse, dens_coarse = eg3d_ops.run_model_rays(planes_hwc, N, dec, o, d, depths_coarse, opts['box_warp'])
+        inj = opts.get('rng_density_noise')                                      # (coarse, fine) draws injected by parity tests
         if opts.get('density_noise', 0) > 0:                                     # renderer.py:149-150
-            dens_coarse = dens_coarse + torch.randn_like(dens_coarse) * opts['density_noise']
+            dens_coarse = dens_coarse + (torch.randn_like(dens_coarse) if inj is None
+                                         else inj[0].reshape(dens_coarse.shape).to(dens_coarse)) * opts['density_noise']
         cc = colors_coarse.reshape(N * M, S, 3)
         sc = dens_coarse.reshape(N * M, S)
         rgb_coarse, depth_coarse, weights_coarse, wsum_coarse = eg3d_ops.march(cc, sc, depths_coarse, wb)
@@ -172,7 +180,8 @@ class ImportanceRenderer(torch.nn.Module):
         depths_fine = eg3d_ops.sample_importance(depths_coarse, weights_coarse, u, F)
         colors_fine, dens_fine = eg3d_ops.run_model_rays(planes_hwc, N, dec, o, d, depths_fine, opts['box_warp'])
         if opts.get('density_noise', 0) > 0:
-            dens_fine = dens_fine + torch.randn_like(dens_fine) * opts['density_noise']
+            dens_fine = dens_fine + (torch.randn_like(dens_fine) if inj is None
+                                     else inj[1].reshape(dens_fine.shape).to(dens_fine)) * opts['density_noise']
         all_d, all_c, all_s = eg3d_ops.unify(depths_coarse, cc, sc, depths_fine, colors_fine.reshape(N * M, F, 3),
                                              dens_fine.reshape(N * M, F))
         rgb_final, depth_final, _, wsum = eg3d_ops.march(all_c, all_s, all_d, wb)

@@ -1023,10 +1023,11 @@ def test_eg3d_draws_on_device(dev, osg):
     assert float((g1 - g2).double().norm() / g2.double().norm()) < 1e-6 and float(g1.abs().max()) > 0
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_eg3d_backward(golden, dev, osg, tag):
     """loss.backward() through ImportanceRenderer: gradients w.r.t. planes and OSGDecoder parameters against
-    the reference's autograd (tools/make_golden.py g_eg3d_grad)."""
+    the reference's autograd (tools/make_golden.py g_eg3d_grad).  Case c: density_noise = 0.35 in training mode
+    (renderer.py:149-150), the reference's two randn_like draws injected."""
     from nerf_siren_amd import ImportanceRenderer
     g = golden("g16_eg3d_grad_" + tag)
     res_ = int(g["res"])
@@ -1035,7 +1036,11 @@ def test_eg3d_backward(golden, dev, osg, tag):
         p.grad = None
     opts = dict(synth.EG3D_OPTIONS, white_back=bool(g["white_back"]), rng_stratified=T(g["rand_strat"], dev),
                 rng_importance=T(g["u"], dev))
+    if "density_noise" in g and float(g["density_noise"]) > 0:
+        opts.update(density_noise=float(g["density_noise"]), rng_density_noise=(T(g["dn_coarse"], dev), T(g["dn_fine"], dev)))
     res = ImportanceRenderer()(planes, osg, T(g["ray_o"][None], dev), T(g["ray_d"][None], dev), opts)
+    for i, nm in enumerate(("rgb_c", "depth_c", "op_c", "rgb_f", "depth_f", "op_f")):
+        np.testing.assert_allclose(N(res[i]), g[nm], rtol=2e-4, atol=2e-4, err_msg=nm)
     t = T(g["target"], dev)
     loss = ((res[0] - t) ** 2).mean() + ((res[3] - t) ** 2).mean() + 0.05 * res[1].mean() + 0.02 * (res[4] ** 2).mean() \
         + 0.3 * res[2].mean() - 0.2 * res[5].mean()

@@ -466,21 +466,33 @@ def g_eg3d_grad():
     dec = OSGDecoder(32, {"decoder_lr_mul": 1.0, "decoder_output_dim": 3})
     dec.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.osg_params(4).items()})
     ren = ImportanceRenderer()
-    for tag, wb, res_ in (("a", False, 32), ("b", True, 16)):
+    # case c: density_noise > 0 (renderer.py:149-150: sigma += randn_like(sigma) * density_noise in both run_model calls); the two
+    # draws are captured (coarse call first, then the fine one) so that the HIP path can be fed the same noise
+    for tag, wb, res_, dnoise in (("a", False, 32, 0.0), ("b", True, 16, 0.0), ("c", False, 32, 0.35)):
         opts = dict(synth.EG3D_OPTIONS, white_back=wb)
+        if dnoise > 0:
+            opts["density_noise"] = dnoise
+        drawn = []
         planes = torch.from_numpy(synth.triplanes(8, res=res_)).requires_grad_(True)
         M = 40
         o, d = synth.eg3d_rays(M, 71)
         rs = synth.hash_uniform((1, M, 64, 1), 730)
         u2 = synth.hash_uniform((M, 64), 731)
         tgt = synth.hash_uniform((1, M, 3), 732)
-        _rand, _rl = torch.rand, torch.rand_like
+        _rand, _rl, _rnl = torch.rand, torch.rand_like, torch.randn_like
+
+        def _randn_like(t, **k):
+            n = torch.from_numpy(synth.hash_normal(tuple(t.shape), 740 + len(drawn)))
+            drawn.append(n.numpy().copy())
+            return n
         torch.rand = lambda *a, **k: torch.from_numpy(u2.copy())
         torch.rand_like = lambda t, **k: torch.from_numpy(rs.copy())
+        torch.randn_like = _randn_like
         try:
             res = ren(planes, dec, torch.from_numpy(o[None]), torch.from_numpy(d[None]), opts)
         finally:
-            torch.rand, torch.rand_like = _rand, _rl
+            torch.rand, torch.rand_like, torch.randn_like = _rand, _rl, _rnl
+        assert len(drawn) == (2 if dnoise > 0 else 0)
         t = torch.from_numpy(tgt)
         loss = ((res[0] - t) ** 2).mean() + ((res[3] - t) ** 2).mean() + 0.05 * res[1].mean() + 0.02 * (res[4] ** 2).mean() \
             + 0.3 * res[2].mean() - 0.2 * res[5].mean()
@@ -489,6 +501,7 @@ def g_eg3d_grad():
         loss.backward()
         gp = planes.grad.numpy()
         out = dict(ray_o=o, ray_d=d, rand_strat=rs, u=u2, target=tgt, white_back=wb, res=res_, loss=loss.detach(),
+                   density_noise=np.float32(dnoise), **({"dn_coarse": drawn[0], "dn_fine": drawn[1]} if dnoise > 0 else {}),
                    gplanes_sub=gp.reshape(-1)[::7].copy(), gplanes_norm=np.linalg.norm(gp.astype(np.float64)),
                    gplanes_nnz=(gp != 0).sum())
         for k, p in dec.named_parameters():
