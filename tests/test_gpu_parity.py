@@ -418,11 +418,12 @@ def test_render_rays_full_size_properties(dev, models):
 
 # --------------------------------------------------------------------------- backward
 @pytest.mark.parametrize("fwd", ["fp32", "bf16x3"])
-@pytest.mark.parametrize("n_rays,P", [(3, 64), (2, 128), (5, 24), (1, 1), (9, 37)])
+@pytest.mark.parametrize("n_rays,P", [(3, 64), (2, 128), (5, 24), (1, 1), (9, 37), (12, 64), (7, 96)])
 def test_nerf_backward_kernels_vs_oracle(ops, dev, models, n_rays, P, fwd):
     """dX chain + dW GEMM + slab reduce against the oracle's manual backward on the same
     (points, dL/d[rgb,sigma]); ragged point counts (n_points % 32 != 0).  fwd = bf16x3: the activations saved by the
-    split-bf16 forward feed the backward whose dX chain also runs on the split-bf16 path."""
+    split-bf16 forward feed the backward whose dX chain also runs on the split-bf16 path.  The last two sizes (24 and 21 tiles)
+    give the dW GEMM's small tasks 2-6 tiles per workgroup: fewer than, as many as and more than the depth of their LDS-DMA rings."""
     params, ms = models
     rays = synth.blender_rays(n_rays, 21)
     z = np.sort(synth.hash_uniform((n_rays, P), 22) * 4 + 2, -1).astype(np.float32)
@@ -789,7 +790,7 @@ def test_siren_conditioning_gradients_vs_reference_autograd(golden, dev, siren):
 
 
 @pytest.mark.parametrize("math", ["fp32", "bf16x3"])
-@pytest.mark.parametrize("n_rays", [37, 200])
+@pytest.mark.parametrize("n_rays", [6, 37, 200])      # 6 rays: 12 / 24 tiles = 3 / 6 per workgroup of the dW GEMM's small tasks
 def test_siren_render_rays_training(dev, n_rays, math):
     """render_rays([SirenField, SirenField]) in training mode (perturb, noise, white_back) against the oracle pipeline:
     outputs, and the gradients of both fields' 22 parameters (compositor backward -> SIREN backward).  The fine
